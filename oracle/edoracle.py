@@ -1,0 +1,166 @@
+"""ctypes front-end of the CPU checker (oracle/libed_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (exomedepth_amd) never does.  See oracle/ed_oracle.c for what is restated and how
+it is pinned to the reference.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+LIBM, PORTABLE = 0, 1
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_bp = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """(Re)build the checker -- and oracle/_ref when /root/reference is present -- with make."""
+    so = os.path.join(_HERE, "libed_oracle.so")
+    if force or not os.path.exists(so) or os.path.exists("/root/reference/src/beta.c"):
+        subprocess.run(["make", "-C", _HERE, "--no-print-directory"], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libed_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        for name in ("edo_plog_v", "edo_pexp_v", "edo_psin_v"):
+            getattr(L, name).argtypes = [C.c_long, _dp, _dp]
+            getattr(L, name).restype = None
+        L.edo_lnbeta_v.argtypes = [C.c_int, C.c_long, _dp, _dp, _dp]
+        L.edo_lnbeta_v.restype = C.c_long
+        L.edo_sf_v.argtypes = [C.c_int, C.c_int, C.c_long, _dp, _dp, _ip]
+        L.edo_sf_v.restype = None
+        L.edo_get_loglike_matrix.argtypes = [C.c_int, _dp, _dp, _ip, _ip, C.c_long, C.c_double, _dp]
+        L.edo_get_loglike_matrix.restype = C.c_long
+        L.edo_hmm.argtypes = [C.c_int, C.c_long, _dp, _dp, _ip, C.c_double, _dp, _dp, C.c_long]
+        L.edo_hmm.restype = C.c_long
+        L.edo_callcnvs.argtypes = [_dp, C.c_long, _ip, C.c_int, _ip, _ip, C.c_double, C.c_double, _bp, _dp, C.c_long]
+        L.edo_callcnvs.restype = C.c_long
+        L.edo_ref_open.argtypes = [C.c_char_p]
+        L.edo_ref_open.restype = C.c_int
+        L.edo_ref_call1.argtypes = [C.c_char_p, C.c_long, _dp, _dp]
+        L.edo_ref_call1.restype = C.c_int
+        L.edo_ref_call2.argtypes = [C.c_char_p, C.c_long, _dp, _dp, _dp]
+        L.edo_ref_call2.restype = C.c_int
+        L.edo_now.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def plog(x):
+    x = _f64(x); out = np.empty_like(x); lib().edo_plog_v(x.size, x, out); return out
+
+
+def pexp(x):
+    x = _f64(x); out = np.empty_like(x); lib().edo_pexp_v(x.size, x, out); return out
+
+
+def psin(x):
+    x = _f64(x); out = np.empty_like(x); lib().edo_psin_v(x.size, x, out); return out
+
+
+def lnbeta(x, y, flavour=PORTABLE):
+    x = _f64(x); y = _f64(y); out = np.empty_like(x)
+    lib().edo_lnbeta_v(flavour, x.size, x, y, out)
+    return out
+
+
+_SF = {"lngamma": 0, "gammastar": 1, "log_1plusx": 2, "lngamma_e": 3}
+
+
+def sf(which, x, flavour=PORTABLE):
+    x = _f64(x); out = np.empty_like(x); st = np.zeros(x.size, dtype=np.int32)
+    lib().edo_sf_v(flavour, _SF[which], x.size, x, out, st)
+    return out, st
+
+
+def get_loglike_matrix(phi, expected, total, observed, mixture=1.0, flavour=PORTABLE):
+    """reference src/CNV_estimate.cpp:52-85 -> (n,3) array, columns (deletion, normal, duplication)."""
+    total = _i32(total); n = total.size
+    phi = _f64(np.broadcast_to(phi, (n,))); expected = _f64(np.broadcast_to(expected, (n,)))
+    observed = _i32(observed)
+    out = np.empty((3, n), dtype=np.float64)  # column-major n x 3
+    nerr = lib().edo_get_loglike_matrix(flavour, phi, expected, total, observed, n, float(mixture), out)
+    return out.T, nerr
+
+
+def hmm(transitions, loglikelihood, positions, expected_cnv_length, nstates=3):
+    """reference R/tools.R:88-103 + src/hmm.cpp:18-167.  loglikelihood: (nobs,3) in HMM order
+    (normal, deletion, duplication).  Returns (path int array, calls (ncalls,4) float array)."""
+    T = np.asarray(transitions, dtype=np.float64)
+    if T.shape[0] != T.shape[1]:
+        raise ValueError("Transition matrix is not square")
+    ll = np.asarray(loglikelihood, dtype=np.float64)
+    positions = _i32(positions)
+    if positions.size != ll.shape[0]:
+        raise ValueError("The number of positions are not matching the number of rows of the likelihood matrix")
+    nobs = ll.shape[0]
+    Tc = _f64(T.T.ravel())       # column-major
+    llc = _f64(ll.T.ravel())     # column-major nobs x 3
+    path = np.empty(nobs, dtype=np.float64)
+    cap = max(nobs, 1)
+    calls = np.zeros((cap, 4), dtype=np.float64)
+    nc = lib().edo_hmm(int(nstates), nobs, Tc, llc, positions, float(expected_cnv_length), path, calls, cap)
+    if nc < 0:
+        return None
+    return path.astype(np.int64), calls[:nc].copy()
+
+
+def callcnvs(likelihood, chrom_off, start, end, transition_probability=1e-4, expected_cnv_length=50000.0):
+    """reference R/class_definition.R:343-374, :408-414 on pre-ordered exons.  likelihood (n,3) in
+    (deletion, normal, duplication) order.  Returns (path int8[n], calls (ncalls,4))."""
+    ll = np.asarray(likelihood, dtype=np.float64)
+    n = ll.shape[0]
+    llc = _f64(ll.T.ravel())
+    chrom_off = _i32(chrom_off)
+    path = np.zeros(n, dtype=np.int8)
+    cap = n + 8
+    calls = np.zeros((cap, 4), dtype=np.float64)
+    nc = lib().edo_callcnvs(llc, n, chrom_off, chrom_off.size - 1, _i32(start), _i32(end),
+                            float(transition_probability), float(expected_cnv_length), path, calls, cap)
+    return path, calls[:nc].copy()
+
+
+# ---- the reference's own special functions, compiled as they lie (container only) ----
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libgslsf_ref.so"))
+
+
+def _ref_open():
+    if lib().edo_ref_open(os.path.join(_HERE, "_ref", "libgslsf_ref.so").encode()) != 0:
+        raise RuntimeError("oracle/_ref/libgslsf_ref.so not loadable")
+
+
+def ref_call1(name, x):
+    _ref_open()
+    x = _f64(x); out = np.empty_like(x)
+    if lib().edo_ref_call1(name.encode(), x.size, x, out) != 0:
+        raise RuntimeError("reference symbol %s not found" % name)
+    return out
+
+
+def ref_call2(name, x, y):
+    _ref_open()
+    x = _f64(x); y = _f64(y); out = np.empty_like(x)
+    if lib().edo_ref_call2(name.encode(), x.size, x, y, out) != 0:
+        raise RuntimeError("reference symbol %s not found" % name)
+    return out
