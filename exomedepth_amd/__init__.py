@@ -1,0 +1,11 @@
+"""exomedepth_amd -- MI355X (gfx950) CNV-calling core: beta-binomial emissions + 3-state Viterbi.
+
+Only what the hot path needs lives here: csrc/ (HIP kernels + the C-ABI of include/exomedepth_amd.h)
+and the host-side mirror of the reference's interface for this path (api.py).
+"""
+from ._lib import EdError, LIB_PATH  # noqa: F401
+from .api import (Batch, DeviceArray, ExomeDepth, Plan, chromosome_order, fit_betabin,  # noqa: F401
+                  get_loglike_matrix, viterbi_hmm)
+
+__all__ = ["Batch", "DeviceArray", "ExomeDepth", "Plan", "EdError", "chromosome_order", "fit_betabin",
+           "get_loglike_matrix", "viterbi_hmm", "LIB_PATH"]

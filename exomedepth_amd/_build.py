@@ -1,0 +1,49 @@
+"""Build libedcore.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libedcore.so")
+SOURCES = ["edcore.hip"]
+DEPS = ["edcore.hip", "ed_sf_dev.hpp", "ed_pmath.h", "ed_fit_dev.hpp", "../../include/exomedepth_amd.h"]
+# -ffp-contract=off is part of the numerical contract (see csrc/ed_pmath.h): no implicit fma.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-fvisibility=hidden"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for d in DEPS:
+        p = os.path.join(CSRC, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(" ".join(cmd))
+        print(r.stdout)
+        print(r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed building libedcore.so")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,80 @@
+"""ctypes binding of libedcore.so (the C-ABI declared in include/exomedepth_amd.h).
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950 device is usable,
+every compute entry raises.  The CPU checker under oracle/ is test infrastructure and is never
+imported from here.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libedcore.so")
+
+ED_OK = 0
+
+
+class EdError(RuntimeError):
+    pass
+
+
+class EdCall(C.Structure):
+    _fields_ = [("sample", C.c_int32), ("chrom", C.c_int32), ("start_exon", C.c_int32), ("end_exon", C.c_int32),
+                ("type", C.c_int32), ("nexons", C.c_int32)]
+
+
+_lib = None
+
+# every symbol include/exomedepth_amd.h declares: (name, restype, argtypes)
+_vp, _i64, _i32, _dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+SYMBOLS = [
+    ("ed_version", C.c_char_p, []),
+    ("ed_last_error", C.c_char_p, []),
+    ("ed_device_count", C.c_int, []),
+    ("ed_device_info", C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    ("ed_get_loglike_matrix", C.c_int, [_vp, _vp, _vp, _vp, _i64, _dbl, _vp, C.POINTER(_i64)]),
+    ("ed_hmm", C.c_int, [_i32, _i32, _vp, _vp, _vp, _dbl, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("ed_plan_create", C.c_int, [C.POINTER(_vp), C.c_int, _i64, _i32, _vp, _vp, _vp, _dbl, _dbl]),
+    ("ed_plan_destroy", None, [_vp]),
+    ("ed_plan_n_exons", _i64, [_vp]),
+    ("ed_batch_create", C.c_int, [C.POINTER(_vp), _vp, _i64]),
+    ("ed_batch_destroy", None, [_vp]),
+    ("ed_batch_fit", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ed_batch_run", C.c_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp]),
+    ("ed_batch_loglik", _vp, [_vp]),
+    ("ed_batch_path", _vp, [_vp]),
+    ("ed_batch_calls", _vp, [_vp]),
+    ("ed_batch_n_calls", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("ed_batch_n_gsl_errors", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("ed_batch_copy_calls", C.c_int, [_vp, _vp, _i64]),
+    ("ed_batch_copy_path", C.c_int, [_vp, _vp]),
+    ("ed_batch_copy_loglik", C.c_int, [_vp, _vp]),
+    ("ed_batch_enable_timing", C.c_int, [_vp, C.c_int]),
+    ("ed_batch_stage_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("ed_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    ("ed_free", C.c_int, [_vp]),
+    ("ed_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("ed_memcpy_d2h", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("ed_synchronize", C.c_int, [_vp]),
+    ("ed_eval_sf", C.c_int, [C.c_int, _i64, _vp, _vp, _vp]),
+]
+
+
+def lib():
+    """Load libedcore.so; raise loudly if it is not there (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EdError("exomedepth_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != ED_OK:
+        raise EdError("libedcore: %s (status %d)" % (lib().ed_last_error().decode(errors="replace"), rc))

@@ -1,0 +1,422 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C-ABI (libedcore.so).
+
+Names, argument meaning and error behaviour follow the reference's R layer so that the parity tests
+read like the reference's own examples:
+
+    get_loglike_matrix(...)   <- .Call("get_loglike_matrix", ...)      reference R/class_definition.R:184-189
+    viterbi_hmm(...)          <- viterbi.hmm()                         reference R/tools.R:88-103
+    ExomeDepth(...)           <- new('ExomeDepth', test=, reference=)  reference R/class_definition.R:82-191
+    ExomeDepth.CallCNVs(...)  <- CallCNVs()                            reference R/class_definition.R:311-419
+    ExomeDepth.TestCNV(...)   <- TestCNV()                             reference R/class_definition.R:243-256
+    Plan / Batch              the batched, device-resident interface (no counterpart in the reference,
+                              whose granularity is one sample and one chromosome per call)
+
+All arithmetic of the path runs on the GPU; this module only marshals buffers (numpy on the host,
+optionally torch CUDA tensors for device-resident inputs).
+"""
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import EdCall, EdError, check, lib
+
+CALL_DTYPE = np.dtype([("sample", "<i4"), ("chrom", "<i4"), ("start_exon", "<i4"), ("end_exon", "<i4"),
+                       ("type", "<i4"), ("nexons", "<i4")])
+assert CALL_DTYPE.itemsize == C.sizeof(EdCall)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _as_r_integer(x):
+    """R's as.integer() on a numeric vector: truncation toward zero (R/class_definition.R:187-188)."""
+    a = np.asarray(x)
+    if a.dtype.kind in "iu":
+        return a.astype(np.int32)
+    return np.trunc(a).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# the two .Call drop-ins
+# ---------------------------------------------------------------------------------------------
+def get_loglike_matrix(phi, expected, total, observed, mixture=1.0, return_errors=False):
+    """Per-exon log-likelihoods of the three copy-number states; (n,3) array with columns
+    (deletion, normal, duplication) -- reference src/CNV_estimate.cpp:52-85."""
+    total = _i32(total)
+    n = total.size
+    phi = _f64(np.broadcast_to(np.asarray(phi, dtype=np.float64), (n,)))
+    expected = _f64(np.broadcast_to(np.asarray(expected, dtype=np.float64), (n,)))
+    observed = _i32(observed)
+    if observed.size != n:
+        raise ValueError("total and observed must have the same length")
+    if mixture != 1:
+        # reference src/CNV_estimate.cpp:61
+        sys.stdout.write("As a warning (this could be normal), the mixture coefficient is %f\n" % mixture)
+    out = np.empty((3, n), dtype=np.float64)  # column-major n x 3
+    nerr = C.c_int64(0)
+    check(lib().ed_get_loglike_matrix(_ptr(phi), _ptr(expected), _ptr(total), _ptr(observed), n, float(mixture),
+                                      _ptr(out), C.byref(nerr)))
+    return (out.T, nerr.value) if return_errors else out.T
+
+
+def viterbi_hmm(transitions, loglikelihood, positions, expected_CNV_length):
+    """reference R/tools.R:88-103.  loglikelihood: (nobs, nstates) in HMM order (normal, deletion,
+    duplication).  Returns {'Viterbi.path': int array, 'calls': structured array with fields
+    start.p, end.p, type, nexons} (1-based positions like the reference)."""
+    T = np.asarray(transitions, dtype=np.float64)
+    ll = np.asarray(loglikelihood, dtype=np.float64)
+    if T.ndim != 2 or T.shape[0] != T.shape[1]:
+        raise ValueError("Transition matrix is not square")
+    positions = _i32(positions)
+    if positions.size != ll.shape[0]:
+        raise ValueError("The number of positions are not matching the number of rows of the likelihood matrix "
+                         "%d and %d" % (positions.size, ll.shape[0]))
+    nstates, nobs = T.shape[0], ll.shape[0]
+    Tc = _f64(T.T.ravel())
+    llc = _f64(ll.T.ravel())
+    path = np.empty(nobs, dtype=np.float64)
+    cap = max(nobs, 1)
+    calls = np.zeros((4, cap), dtype=np.float64)  # column-major cap x 4
+    nc = C.c_int64(0)
+    check(lib().ed_hmm(nstates, nobs, _ptr(Tc), _ptr(llc), _ptr(positions), float(expected_CNV_length), _ptr(path),
+                       _ptr(calls), cap, C.byref(nc)))
+    k = nc.value
+    rec = np.zeros(k, dtype=[("start.p", "f8"), ("end.p", "f8"), ("type", "f8"), ("nexons", "f8")])
+    for j, name in enumerate(rec.dtype.names):
+        rec[name] = calls[j, :k]
+    return {"Viterbi.path": path.astype(np.int64), "calls": rec}
+
+
+# ---------------------------------------------------------------------------------------------
+# device buffers
+# ---------------------------------------------------------------------------------------------
+class DeviceArray:
+    """A device allocation made through the library (for callers without torch)."""
+
+    def __init__(self, host=None, nbytes=None):
+        self.ptr = C.c_void_p()
+        self.host_dtype = None
+        self.shape = None
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            nbytes = host.nbytes
+            self.host_dtype, self.shape = host.dtype, host.shape
+        self.nbytes = int(nbytes)
+        check(lib().ed_malloc(C.byref(self.ptr), self.nbytes))
+        if host is not None and self.nbytes:
+            check(lib().ed_memcpy_h2d(self.ptr, _ptr(host), self.nbytes))
+
+    def to_host(self, dtype=None, shape=None):
+        out = np.empty(shape if shape is not None else self.shape, dtype=dtype if dtype is not None else self.host_dtype)
+        if out.nbytes:
+            check(lib().ed_memcpy_d2h(_ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().ed_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _device_pointer(x, dtype, keep):
+    """Return a c_void_p for x: a torch CUDA tensor (used in place), a DeviceArray, or host data
+    (uploaded; the temporary is appended to `keep`)."""
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
+        if not x.is_cuda:
+            x = x.cuda()
+            keep.append(x)
+        if not x.is_contiguous():
+            raise ValueError("device tensors must be contiguous")
+        want = {np.dtype(np.int32): "torch.int32", np.dtype(np.float64): "torch.float64"}[np.dtype(dtype)]
+        if str(x.dtype) != want:
+            raise ValueError("expected a %s tensor, got %s" % (want, x.dtype))
+        return C.c_void_p(x.data_ptr())
+    d = DeviceArray(np.ascontiguousarray(x, dtype=dtype))
+    keep.append(d)
+    return d.ptr
+
+
+class Plan:
+    """Exon design + HMM parameters (CallCNVs arguments, reference R/class_definition.R:261, :311).
+    Exons must be ordered by (chromosome, position); chrom_off delimits the chromosomes."""
+
+    def __init__(self, chrom_off, start, end, transition_probability=1e-4, expected_CNV_length=50000.0, device=0):
+        self.chrom_off = _i32(chrom_off)
+        self.start = _i32(start)
+        self.end = _i32(end)
+        self.n_exons = int(self.start.size)
+        self.n_chrom = int(self.chrom_off.size - 1)
+        self.transition_probability = float(transition_probability)
+        self.expected_CNV_length = float(expected_CNV_length)
+        self.handle = C.c_void_p()
+        check(lib().ed_plan_create(C.byref(self.handle), int(device), self.n_exons, self.n_chrom, _ptr(self.chrom_off),
+                                   _ptr(self.start), _ptr(self.end), self.transition_probability,
+                                   self.expected_CNV_length))
+
+    def close(self):
+        if self.handle:
+            lib().ed_plan_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """Device working set for n_samples samples of a plan.  Count matrices are int32
+    [n_exons][n_samples] (sample-minor)."""
+
+    STAGES = ("sample_consts", "emissions", "viterbi", "call_table", "fit")
+
+    def __init__(self, plan, n_samples):
+        self.plan = plan
+        self.n_samples = int(n_samples)
+        self.handle = C.c_void_p()
+        self._keep = []
+        check(lib().ed_batch_create(C.byref(self.handle), plan.handle, self.n_samples))
+
+    def close(self):
+        if self.handle:
+            lib().ed_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enable_timing(self, on=True):
+        check(lib().ed_batch_enable_timing(self.handle, 1 if on else 0))
+
+    def fit(self, test, ref, phi_out, expected_out, stream=None):
+        """Per-sample beta-binomial fit (phi, expected) -- counterpart of aod::betabin at reference
+        R/class_definition.R:118.  phi_out/expected_out: device float64[n_samples]."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi_out, np.float64, keep)
+        pe = _device_pointer(expected_out, np.float64, keep)
+        self._keep = keep
+        check(lib().ed_batch_fit(self.handle, pt, pr, pp, pe, C.c_void_p(stream or 0)))
+
+    def run(self, test, ref, phi, expected, mixture=1.0, stream=None):
+        """Emissions + Viterbi + call table.  Arguments may be torch CUDA tensors (used in place),
+        DeviceArrays, or host arrays (uploaded).  Asynchronous on `stream`."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi, np.float64, keep)
+        pe = _device_pointer(expected, np.float64, keep)
+        self._keep = keep  # keep temporaries alive until the next run
+        check(lib().ed_batch_run(self.handle, pt, pr, pp, pe, float(mixture), C.c_void_p(stream or 0)))
+
+    # ---- results ----
+    def n_calls(self):
+        n = C.c_int64(0)
+        check(lib().ed_batch_n_calls(self.handle, C.byref(n)))
+        return n.value
+
+    def n_gsl_errors(self):
+        n = C.c_int64(0)
+        check(lib().ed_batch_n_gsl_errors(self.handle, C.byref(n)))
+        return n.value
+
+    def calls(self):
+        n = self.n_calls()
+        out = np.zeros(n, dtype=CALL_DTYPE)
+        check(lib().ed_batch_copy_calls(self.handle, _ptr(out), n))
+        return out
+
+    def path(self):
+        out = np.empty((self.plan.n_exons, self.n_samples), dtype=np.uint8)
+        check(lib().ed_batch_copy_path(self.handle, _ptr(out)))
+        return out
+
+    def loglik(self):
+        """(n_exons, 3, n_samples): [:,0,:] deletion, [:,1,:] normal, [:,2,:] duplication."""
+        out = np.empty((self.plan.n_exons, 3, self.n_samples), dtype=np.float64)
+        check(lib().ed_batch_copy_loglik(self.handle, _ptr(out)))
+        return out
+
+    def device_pointers(self):
+        L = lib()
+        return {"loglik": L.ed_batch_loglik(self.handle), "path": L.ed_batch_path(self.handle),
+                "calls": L.ed_batch_calls(self.handle)}
+
+    def stage_ms(self):
+        ms = (C.c_float * 5)()
+        check(lib().ed_batch_stage_ms(self.handle, ms))
+        return dict(zip(self.STAGES, [float(v) for v in ms]))
+
+
+# ---------------------------------------------------------------------------------------------
+# exon ordering of CallCNVs (reference R/class_definition.R:323-336)
+# ---------------------------------------------------------------------------------------------
+def chromosome_order(chromosome, start, end):
+    """Return (order, chrom_levels, chrom_codes_sorted, chrom_off).  Levels are '1'..'22' first (those
+    present), then the other names in first-seen order; exons are ordered by (level, midpoint) with
+    ties kept in input order, as R's order() does."""
+    chromosome = np.asarray([str(c) for c in chromosome], dtype=object)
+    used = []
+    seen = set()
+    for c in chromosome:
+        if c not in seen:
+            seen.add(c)
+            used.append(c)
+    autos = [str(i) for i in range(1, 23)]
+    levels = [c for c in autos if c in seen] + [c for c in used if c not in autos]
+    code_of = {c: i for i, c in enumerate(levels)}
+    codes = np.fromiter((code_of[c] for c in chromosome), dtype=np.int64, count=chromosome.size)
+    mid = 0.5 * (np.asarray(start, dtype=np.float64) + np.asarray(end, dtype=np.float64))
+    order = np.lexsort((mid, codes))  # stable: last key is primary
+    sc = codes[order]
+    chrom_off = np.zeros(len(levels) + 1, dtype=np.int32)
+    for i in range(len(levels)):
+        chrom_off[i + 1] = chrom_off[i] + int(np.sum(sc == i))
+    return order, levels, sc, chrom_off
+
+
+class ExomeDepth:
+    """Mirror of the reference's S4 class (R/class_definition.R:36-46) for one test sample.
+
+    phi / expected: if given, the fixed dispersion and expected proportion (the reference gets them
+    from aod::betabin, :118, :168); if omitted they are fitted on the GPU (ed_batch_fit)."""
+
+    def __init__(self, test, reference, phi=None, expected=None, prop_tumor=1.0, verbose=False):
+        test = np.asarray(test, dtype=np.float64)
+        reference = np.asarray(reference, dtype=np.float64)
+        if test.size != reference.size:
+            raise ValueError("Length of test and numeric must match")   # R/class_definition.R:92
+        self.test, self.reference = test, reference
+        self.phi = np.zeros(0)
+        self.expected = np.zeros(0)
+        self.likelihood = np.zeros((0, 3))
+        self.annotations = None
+        self.CNV_calls = None
+        self.cor_test_reference = None
+        if np.sum(test > 5) < 5:                                       # R/class_definition.R:94-97
+            if verbose:
+                print("It looks like the test samples has only %d bins with more than 5 reads." % np.sum(test > 5))
+            return
+        n = test.size
+        if phi is None or expected is None:
+            phi, expected = fit_betabin(_as_r_integer(test), _as_r_integer(reference))
+        self.phi = np.full(n, float(phi)) if np.ndim(phi) == 0 else _f64(phi)
+        self.expected = np.full(n, float(expected)) if np.ndim(expected) == 0 else _f64(expected)
+        self.likelihood = np.array(get_loglike_matrix(self.phi, self.expected, _as_r_integer(reference + test),
+                                                      _as_r_integer(test), mixture=prop_tumor))
+
+    def TestCNV(self, chromosome, start, end, type):
+        """reference R/class_definition.R:243-256 (needs CallCNVs annotations for the positions)."""
+        if type not in ("deletion", "duplication"):
+            raise ValueError("type must be either duplication or deletion\n")
+        if self.annotations is None:
+            raise ValueError("This function cannot be used if the position of the exons/DNA segments was not included")
+        a = self.annotations
+        which = (a["chromosome"] == str(chromosome)) & (a["start"] >= start) & (a["end"] <= end)
+        col = 0 if type == "deletion" else 2
+        return float(np.sum(self.likelihood[which, col] - self.likelihood[which, 1]))
+
+    def CallCNVs(self, chromosome, start, end, name, transition_probability=1e-4, expected_CNV_length=50000):
+        """reference R/class_definition.R:311-419: order exons, one Viterbi chain per chromosome,
+        call table with start.p/end.p (1-based, global), type, nexons, start, end, chromosome, id."""
+        if self.phi.size == 0:
+            self.CNV_calls = []
+            return self
+        n = self.likelihood.shape[0]
+        if not (len(start) == len(chromosome) == len(end) == len(name)):
+            raise ValueError("Chromosome, name, start and end vector must have the same lengths.\n")
+        if n != len(chromosome):
+            raise ValueError("The annotation vectors must have the same length as the data in the ExomeDepth x")
+        order, levels, codes, chrom_off = chromosome_order(chromosome, start, end)
+        start = np.asarray(start)[order]
+        end = np.asarray(end)[order]
+        name = np.asarray(name, dtype=object)[order]
+        chrom_sorted = np.asarray([str(c) for c in chromosome], dtype=object)[order]
+        if np.any(order != np.arange(n)):
+            self.test = self.test[order]
+            self.reference = self.reference[order]
+            self.likelihood = self.likelihood[order]
+            self.phi = self.phi[order]
+            self.expected = self.expected[order]
+        self.annotations = {"name": name, "chromosome": chrom_sorted, "start": start, "end": end}
+        self.cor_test_reference = float(np.corrcoef(self.test, self.reference)[0, 1])
+        plan = Plan(chrom_off, start, end, transition_probability, expected_CNV_length)
+        batch = Batch(plan, 1)
+        try:
+            # the likelihood is recomputed on the device from the same inputs (bit-identical to the slot)
+            batch.run(_as_r_integer(self.test).reshape(n, 1), _as_r_integer(self.reference).reshape(n, 1),
+                      self.phi[:1], self.expected[:1])
+            raw = batch.calls()
+            self.Viterbi_path = batch.path()[:, 0].astype(np.int64)
+        finally:
+            batch.close()
+            plan.close()
+        calls = []
+        total = self.test + self.reference
+        for r in raw:
+            s, e = int(r["start_exon"]), int(r["end_exon"])
+            typ = ["deletion", "duplication"][int(r["type"]) - 1]
+            col = 0 if typ == "deletion" else 2
+            bf = float(np.sum(self.likelihood[s:e + 1, col] - self.likelihood[s:e + 1, 1]))
+            reads_expected = int(np.sum(total[s:e + 1] * self.expected[s:e + 1]))
+            reads_observed = float(np.sum(self.test[s:e + 1]))
+            cid = ("chr%s:%d-%d" % (chrom_sorted[s], start[s], end[e])).replace("chrchr", "chr")
+            calls.append({"start.p": s + 1, "end.p": e + 1, "type": typ, "nexons": int(r["nexons"]),
+                          "start": int(start[s]), "end": int(end[e]), "chromosome": chrom_sorted[s], "id": cid,
+                          "BF": _signif(np.log10(np.e) * bf, 3), "reads.expected": reads_expected,
+                          "reads.observed": reads_observed,
+                          "reads.ratio": _signif(reads_observed / reads_expected, 3) if reads_expected else float("nan")})
+        self.CNV_calls = calls
+        return self
+
+
+def _signif(x, digits):
+    """R's signif() for the call table's BF and reads.ratio (R/class_definition.R:403-404)."""
+    if x == 0 or not np.isfinite(x):
+        return x
+    from math import floor, log10
+    e = digits - 1 - int(floor(log10(abs(x))))
+    return round(x * 10 ** e) / 10 ** e if e >= 0 else round(x / 10 ** (-e)) * 10 ** (-e)
+
+
+def fit_betabin(test, reference):
+    """Fit (phi, expected) of  cbind(test, reference) ~ 1  for one sample on the GPU."""
+    test = _i32(test)
+    reference = _i32(reference)
+    n = test.size
+    plan = Plan(np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32) + 1)
+    batch = Batch(plan, 1)
+    try:
+        phi = DeviceArray(np.zeros(1))
+        exp = DeviceArray(np.zeros(1))
+        batch.fit(test.reshape(n, 1), reference.reshape(n, 1), phi, exp)
+        check(lib().ed_synchronize(None))
+        return float(phi.to_host()[0]), float(exp.to_host()[0])
+    finally:
+        batch.close()
+        plan.close()

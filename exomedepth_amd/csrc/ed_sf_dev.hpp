@@ -1,0 +1,251 @@
+// ed_sf_dev.hpp -- device-side special functions for the beta-binomial emission kernel (gfx950).
+//
+// What is computed: log B(x,y) exactly as the reference computes it -- the same sequence of binary64
+// operations as gsl_sf_lnbeta (reference src/beta.c:49-114) and the functions below it
+// (src/VP_gamma.c:735-756 Lanczos, :928-980 Pade windows, :761-787 small-x series, :986-1007 and
+// :1332-1379 Gamma*, src/VP_log.c:196-232 log(1+x), Clenshaw recurrence src/VP_gamma.c:36-67) -- with
+// log/exp/sin replaced by the portable definitions of ed_pmath.h.  No a*b+c is contracted (the file
+// is built with -ffp-contract=off), so every lane reproduces the CPU checker bit for bit.
+//
+// How it is written: this is not the reference's control flow.  The result/err structs, status
+// plumbing and error printing are gone; tables live in __constant__ memory and are indexed
+// wave-uniformly (scalar loads); the positive domain (all the path can reach with 0 < phi < 1,
+// 0 < expected < 1) is the fast path and everything else funnels into one cold function.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ed_pmath.h"
+
+namespace edsf {
+
+// ---- constants, spelled as the reference spells them (src/gsl_math.h, src/gsl_machine.h) ----
+#define EDSF_M_E 2.71828182845904523536028747135
+#define EDSF_M_PI 3.14159265358979323846264338328
+#define EDSF_M_SQRT2 1.41421356237309504880168872421
+#define EDSF_M_SQRTPI 1.77245385090551602729816748334
+#define EDSF_M_LN2 0.69314718055994530941723212146
+#define EDSF_M_LNPI 1.14472988584940017414342735135
+#define EDSF_LOGROOT2PI 0.9189385332046727418
+#define EDSF_DBL_EPS 2.2204460492503131e-16
+#define EDSF_ROOT4_EPS 1.2207031250000000e-04
+#define EDSF_ROOT6_EPS 2.4607833005759251e-03
+
+// Chebyshev / Lanczos coefficients of the GSL special-function library (mathematical constants;
+// values as at reference src/VP_gamma.c:594-688, src/VP_log.c:73-95).
+__constant__ const double k_gstar_a[30] = {
+    2.16786447866463034423060819465,     -0.05533249018745584258035832802,    0.01800392431460719960888319748,
+    -0.00580919269468937714480019814,    0.00186523689488400339978881560,     -0.00059746524113955531852595159,
+    0.00019125169907783353925426722,     -0.00006124996546944685735909697,    0.00001963889633130842586440945,
+    -6.3067741254637180272515795142e-06, 2.0288698405861392526872789863e-06,  -6.5384896660838465981983750582e-07,
+    2.1108698058908865476480734911e-07,  -6.8260714912274941677892994580e-08, 2.2108560875880560555583978510e-08,
+    -7.1710331930255456643627187187e-09, 2.3290892983985406754602564745e-09,  -7.5740371598505586754890405359e-10,
+    2.4658267222594334398525312084e-10,  -8.0362243171659883803428749516e-11, 2.6215616826341594653521346229e-11,
+    -8.5596155025948750540420068109e-12, 2.7970831499487963614315315444e-12,  -9.1471771211886202805502562414e-13,
+    2.9934720198063397094916415927e-13,  -9.8026575909753445931073620469e-14, 3.2116773667767153777571410671e-14,
+    -1.0518035333878147029650507254e-14, 3.4144405720185253938994854173e-15,  -1.0115153943081187052322643819e-15};
+__constant__ const double k_gstar_b[30] = {
+    0.0057502277273114339831606096782,   0.0004496689534965685038254147807,   -0.0001672763153188717308905047405,
+    0.0000615137014913154794776670946,   -0.0000223726551711525016380862195,  8.0507405356647954540694800545e-06,
+    -2.8671077107583395569766746448e-06, 1.0106727053742747568362254106e-06,  -3.5265558477595061262310873482e-07,
+    1.2179216046419401193247254591e-07,  -4.1619640180795366971160162267e-08, 1.4066283500795206892487241294e-08,
+    -4.6982570380537099016106141654e-09, 1.5491248664620612686423108936e-09,  -5.0340936319394885789686867772e-10,
+    1.6084448673736032249959475006e-10,  -5.0349733196835456497619787559e-11, 1.5357154939762136997591808461e-11,
+    -4.5233809655775649997667176224e-12, 1.2664429179254447281068538964e-12,  -3.2648287937449326771785041692e-13,
+    7.1528272726086133795579071407e-14,  -9.4831735252566034505739531258e-15, -2.3124001991413207293120906691e-15,
+    2.8406613277170391482590129474e-15,  -1.7245370321618816421281770927e-15, 8.6507923128671112154695006592e-16,
+    -3.9506563665427555895391869919e-16, 1.6779342132074761078792361165e-16,  -6.0483153034414765129837716260e-17};
+__constant__ const double k_lopx[21] = {
+    2.16647910664395270521272590407,     -0.28565398551049742084877469679,    0.01517767255690553732382488171,
+    -0.00200215904941415466274422081,    0.00019211375164056698287947962,     -0.00002553258886105542567601400,
+    2.9004512660400621301999384544e-06,  -3.8873813517057343800270917900e-07, 4.7743678729400456026672697926e-08,
+    -6.4501969776090319441714445454e-09, 8.2751976628812389601561347296e-10,  -1.1260499376492049411710290413e-10,
+    1.4844576692270934446023686322e-11,  -2.0328515972462118942821556033e-12, 2.7291231220549214896095654769e-13,
+    -3.7581977830387938294437434651e-14, 5.1107345870861673561462339876e-15,  -7.0722150011433276578323272272e-16,
+    9.7089758328248469219003866867e-17,  -1.3492637457521938883731579510e-17, 1.8657327910677296608121390705e-18};
+
+// Clenshaw recurrence on [-1,1]; the argument map ((2x+1)-1)/2 is kept because it is not an identity
+// in binary64 (reference src/VP_gamma.c:45-46).
+template <int ORDER>
+__device__ __forceinline__ double clenshaw(const double* __restrict__ c, double x)
+{
+  const double y = ((2.0 * x + 1.0) - 1.0) / 2.0;
+  const double y2 = 2.0 * y;
+  double d = 0.0, dd = 0.0;
+#pragma unroll
+  for (int j = ORDER; j >= 1; --j) {
+    const double t = d;
+    d = (y2 * d - dd) + c[j];
+    dd = t;
+  }
+  return (y * d - dd) + 0.5 * c[0];
+}
+
+// log Gamma(x), x >= 0.5 and outside the Pade windows: Lanczos gamma=7 (src/VP_gamma.c:735-756)
+__device__ __forceinline__ double lngamma_lanczos(double x)
+{
+  x -= 1.0;
+  double Ag = 0.99999999999980993227684700473478;
+  Ag += 676.520368121885098567009190444019 / (x + 1.0);
+  Ag += -1259.13921672240287047156078755283 / (x + 2.0);
+  Ag += 771.3234287776530788486528258894 / (x + 3.0);
+  Ag += -176.61502916214059906584551354 / (x + 4.0);
+  Ag += 12.507343278686904814458936853 / (x + 5.0);
+  Ag += -0.13857109526572011689554707 / (x + 6.0);
+  Ag += 9.984369578019570859563e-6 / (x + 7.0);
+  Ag += 1.50563273514931155834e-7 / (x + 8.0);
+  const double term1 = (x + 0.5) * ed_plog((x + 7.5) / EDSF_M_E);
+  const double term2 = EDSF_LOGROOT2PI + ed_plog(Ag);
+  return term1 + (term2 - 7.0);
+}
+
+// (2,2) Pade + correction for log Gamma(1+eps), log Gamma(2+eps), |eps| < 0.01 (src/VP_gamma.c:928-980)
+__device__ __noinline__ double lngamma_pade(double eps, int two)
+{
+  const double n1 = two ? 1.000895834786669227164446568 : -1.0017419282349508699871138440;
+  const double n2 = two ? 4.209376735287755081642901277 : 1.7364839209922879823280541733;
+  const double d1 = two ? 2.618851904903217274682578255 : 1.2433006018858751556055436011;
+  const double d2 = two ? 10.85766559900983515322922936 : 5.0456274100274010152489597514;
+  const double pf = two ? 2.85337998765781918463568869 : 2.0816265188662692474880210318;
+  const double c0 = two ? 0.0001139406357036744 : 0.004785324257581753;
+  const double c1 = two ? -0.0001365435269792533 : -0.01192457083645441;
+  const double c2 = two ? 0.0001067287169183665 : 0.01931961413960498;
+  const double c3 = two ? -0.0000693271800931282 : -0.02594027398725020;
+  const double c4 = two ? 0.0000407220927867950 : 0.03141928755021455;
+  const double num = (eps + n1) * (eps + n2);
+  const double den = (eps + d1) * (eps + d2);
+  const double pade = pf * num / den;
+  const double eps5 = eps * eps * eps * eps * eps;
+  const double corr = eps5 * (c0 + eps * (c1 + eps * (c2 + eps * (c3 + c4 * eps))));
+  return eps * (pade + corr);
+}
+
+// log Gamma for 0 < x < 0.5 (cold): small-x series (:761-787) or reflection (:1180-1199 / :1244-1276).
+// zform selects sin(pi*(1-x)) (gsl_sf_lngamma_e, used by Gamma*) or sin(pi*x) (gsl_sf_lngamma_sgn_e).
+__device__ __noinline__ double lngamma_below_half(double x, bool zform)
+{
+  if (x < 0.02) {
+    const double c1 = -0.07721566490153286061, c2 = -0.01094400467202744461, c3 = 0.09252092391911371098,
+                 c4 = -0.01827191316559981266, c5 = 0.01800493109685479790, c6 = -0.00685088537872380685,
+                 c7 = 0.00399823955756846603, c8 = -0.00189430621687107802, c9 = 0.00097473237804513221,
+                 c10 = -0.00048434392722255893;
+    const double g6 = c6 + x * (c7 + x * (c8 + x * (c9 + x * c10)));
+    const double g = x * (c1 + x * (c2 + x * (c3 + x * (c4 + x * (c5 + x * g6)))));
+    const double gee = (g + 1.0 / (1.0 + x)) + 0.5 * x;
+    return ed_plog(gee / fabs(x));
+  }
+  const double z = 1.0 - x;
+  const double s = ed_psin_0pi(EDSF_M_PI * (zform ? z : x));
+  // for 0.02 <= x < 0.5 : |s| >= sin(0.02 pi) > 0.015 pi, so neither the s==0 nor the near-pole branch applies
+  return EDSF_M_LNPI - (ed_plog(fabs(s)) + lngamma_lanczos(z));
+}
+
+// log Gamma(x) for x > 0 with the reference's window selection (src/VP_gamma.c:1219-1242)
+__device__ __forceinline__ double lngamma_pos(double x, bool zform)
+{
+  if (fabs(x - 1.0) < 0.01) return lngamma_pade(x - 1.0, 0);
+  if (fabs(x - 2.0) < 0.01) return lngamma_pade(x - 2.0, 1);
+  if (x >= 0.5) return lngamma_lanczos(x);
+  return lngamma_below_half(x, zform);
+}
+
+// Gamma*(x) for x >= 10: exp(Stirling series / x) (src/VP_gamma.c:986-1007), and the 4-term form
+// above 1/eps^(1/4) (:1366-1373)
+__device__ __forceinline__ double gammastar_large(double x)
+{
+  if (x < 1.0 / EDSF_ROOT4_EPS) {
+    const double y = 1.0 / (x * x);
+    const double c0 = 1.0 / 12.0, c1 = -1.0 / 360.0, c2 = 1.0 / 1260.0, c3 = -1.0 / 1680.0, c4 = 1.0 / 1188.0,
+                 c5 = -691.0 / 360360.0, c6 = 1.0 / 156.0, c7 = -3617.0 / 122400.0;
+    const double ser = c0 + y * (c1 + y * (c2 + y * (c3 + y * (c4 + y * (c5 + y * (c6 + y * c7))))));
+    return ed_pexp(ser / x);
+  }
+  if (x < 1.0 / EDSF_DBL_EPS) {
+    const double xi = 1.0 / x;
+    return 1.0 + xi / 12.0 * (1.0 + xi / 24.0 * (1.0 - xi * (139.0 / 180.0 + 571.0 / 8640.0 * xi)));
+  }
+  return 1.0;
+}
+
+// Gamma*(x) for 0 < x < 10 (src/VP_gamma.c:1340-1362): less common on the path, kept out of line
+__device__ __noinline__ double gammastar_small(double x)
+{
+  if (x < 0.5) {
+    const double lg = lngamma_pos(x, true);
+    const double lx = ed_plog(x);
+    const double c = 0.5 * (EDSF_M_LN2 + EDSF_M_LNPI);
+    const double lnr = ((lg - (x - 0.5) * lx) + x) - c;
+    return ed_pexp(lnr);
+  }
+  if (x < 2.0) {
+    const double t = 4.0 / 3.0 * (x - 0.5) - 1.0;
+    return clenshaw<29>(k_gstar_a, t);
+  }
+  const double t = 0.25 * (x - 2.0) - 1.0;
+  const double c = clenshaw<29>(k_gstar_b, t);
+  return (c / (x * x) + 1.0) + 1.0 / (12.0 * x);
+}
+
+__device__ __forceinline__ double gammastar_pos(double x) { return x >= 10.0 ? gammastar_large(x) : gammastar_small(x); }
+
+// log(1+x) for 0 < x < 0.2 -- the only range lnbeta's ratio branch produces (src/VP_log.c:204-226)
+__device__ __forceinline__ double log1plusx_ratio(double x)
+{
+  if (x < EDSF_ROOT6_EPS) {
+    const double c1 = -0.5, c2 = 1.0 / 3.0, c3 = -1.0 / 4.0, c4 = 1.0 / 5.0, c5 = -1.0 / 6.0, c6 = 1.0 / 7.0,
+                 c7 = -1.0 / 8.0, c8 = 1.0 / 9.0, c9 = -1.0 / 10.0;
+    const double t = c5 + x * (c6 + x * (c7 + x * (c8 + x * c9)));
+    return x * (1.0 + x * (c1 + x * (c2 + x * (c3 + x * (c4 + x * t)))));
+  }
+  const double t = 0.5 * (8.0 * x + 1.0) / (x + 2.0);
+  return x * clenshaw<20>(k_lopx, t);
+}
+
+// Everything lnbeta can be asked outside x>0, y>0 (zero, negative, NaN arguments).  Value semantics
+// of the reference's natural-prototype wrapper (src/beta.c:161-164, src/eval.h:3-9):
+//   x==0 or y==0                 -> NaN  (domain error, src/beta.c:54-56)
+//   NaN argument                 -> its log-Gamma term is 0.0 (the comparisons of src/VP_gamma.c:1221-1277
+//                                   all fail and the EROUND exit :1278-1283 returns 0), so e.g.
+//                                   lnbeta(NaN,NaN) = 0.0 and lnbeta(NaN,5) = lgamma(5)
+//   negative argument            -> NaN.  DEVIATION for non-integer negatives: the reference evaluates the
+//                                   reflection formula; a negative shape parameter needs phi > 1, which is
+//                                   outside the model's domain (negative integers are NaN in the reference too).
+// *flag is set to 1: in all these cases the reference raises a GSL error (two printed lines per event).
+__device__ __noinline__ double lnbeta_cold(double x, double y, int* flag)
+{
+  *flag = 1;
+  if (x == 0.0 || y == 0.0) return ed_pm_nan();
+  if (x < 0.0 || y < 0.0) return ed_pm_nan();
+  const double xy = x + y;
+  const double lgx = (x != x) ? 0.0 : lngamma_pos(x, false);
+  const double lgy = (y != y) ? 0.0 : lngamma_pos(y, false);
+  const double lgxy = (xy != xy) ? 0.0 : lngamma_pos(xy, false);
+  return (lgx + lgy) - lgxy;
+}
+
+// log B(x,y) with the reference's branch selection (src/beta.c:62-113).  For x,y > 0 both the ratio
+// branch (min/max < 0.2: Gamma* form) and the general branch (three log-Gammas) are value-exact.
+__device__ __forceinline__ double lnbeta(double x, double y, int* flag)
+{
+  if (!(x > 0.0 && y > 0.0)) return lnbeta_cold(x, y, flag);
+  const double mx = (x > y ? x : y);
+  const double mn = (x < y ? x : y);
+  const double rat = mn / mx;
+  if (rat < 0.2) {
+    const double gsx = gammastar_pos(x);
+    const double gsy = gammastar_pos(y);
+    const double gsxy = gammastar_pos(x + y);
+    const double lnopr = log1plusx_ratio(rat);
+    const double lnpre = ed_plog(((gsx * gsy) / gsxy * EDSF_M_SQRT2) * EDSF_M_SQRTPI);
+    const double t1 = mn * ed_plog(rat);
+    const double t2 = 0.5 * ed_plog(mn);
+    const double t3 = ((x + y) - 0.5) * lnopr;
+    return lnpre + ((t1 - t2) - t3);
+  }
+  // +inf arguments reach this point with rat = NaN; the arithmetic below then yields NaN as the
+  // reference's does.
+  const double lgx = lngamma_pos(x, false);
+  const double lgy = lngamma_pos(y, false);
+  const double lgxy = lngamma_pos(x + y, false);
+  return (lgx + lgy) - lgxy;
+}
+
+}  // namespace edsf

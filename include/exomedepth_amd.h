@@ -1,0 +1,162 @@
+/* exomedepth_amd.h -- C-ABI of libedcore.so, the MI355X (gfx950) CNV-calling core.
+ *
+ * Drop-in boundary.  The reference crosses from R into native code at exactly two .Call entries,
+ * registered in reference src/ExomeDepth_init.c:14-18:
+ *     get_loglike_matrix/5   (reference src/CNV_estimate.cpp:52-85, called at R/class_definition.R:184-189)
+ *     C_hmm/6                (reference src/hmm.cpp:18-167,         called at R/tools.R:97)
+ * ed_get_loglike_matrix() and ed_hmm() below are those two entries with the SEXP wrappers peeled off
+ * (plain pointers and sizes; the R shim that re-wraps them is shown in INTEGRATION.md).  They take
+ * HOST buffers, copy in, launch on the GPU, synchronise and copy out inside the call, as a .Call must.
+ *
+ * The reference's granularity -- one sample, one chromosome per call -- cannot fill a GPU, so the
+ * library adds a batched interface (ed_plan_* / ed_batch_*): one plan per exon design, one batch per
+ * slab of samples, device-resident inputs and outputs.  It computes, per (exon, sample) cell, the
+ * same three log-likelihoods, and per (sample, chromosome) chain the same Viterbi path and call
+ * table, as running the two entries above in the loop of reference R/class_definition.R:354-414.
+ *
+ * Conventions: every function returns 0 on success or a negative ed_status; ed_last_error() gives a
+ * message for the calling thread.  No torch / HIP types appear in signatures: device pointers are
+ * plain pointers and a stream is passed as void* (a hipStream_t; NULL = the default stream).
+ * There is no CPU fallback: without a usable gfx950 device every compute entry fails with
+ * ED_ERR_NO_DEVICE.
+ */
+#ifndef EXOMEDEPTH_AMD_H
+#define EXOMEDEPTH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ED_OK = 0,
+  ED_ERR_INVALID = -1,   /* bad argument (NULL pointer, negative size, nstates != 3 ...) */
+  ED_ERR_NO_DEVICE = -2, /* no usable HIP device */
+  ED_ERR_HIP = -3,       /* a HIP runtime call failed; see ed_last_error() */
+  ED_ERR_NOMEM = -4,
+  ED_ERR_STATE = -5      /* call sequence error (e.g. results requested before ed_batch_run) */
+} ed_status;
+
+/* ---- library / device ---- */
+const char* ed_version(void);
+const char* ed_last_error(void);
+int ed_device_count(void);
+/* name[<=256] receives the gcnArchName ("gfx950:sramecc+:xnack-") */
+int ed_device_info(int device, char* name, size_t name_len, int* compute_units, size_t* total_mem);
+
+/* =====================================================================================
+ * 1. Per-sample drop-ins (host buffers) -- the reference's two .Call entries
+ * ===================================================================================== */
+
+/* get_loglike_matrix: reference src/CNV_estimate.cpp:52-85.
+ *   phi[n], expected[n], total[n], observed[n], mixture  -- as the five SEXP arguments (:16)
+ *   out[3*n]  column-major n x 3: column 0 deletion, 1 normal, 2 duplication (:69, :75-77)
+ *   n_gsl_errors (optional) receives the number of events for which the reference would have printed
+ *   a GSL error (src/error.c:45-48): NaN/zero shape parameters.  Values on those rows match the
+ *   reference's (NaN, or 0.0 for NaN inputs). */
+int ed_get_loglike_matrix(const double* phi, const double* expected, const int32_t* total, const int32_t* observed,
+                          int64_t n, double mixture, double* out, int64_t* n_gsl_errors);
+
+/* C_hmm: reference src/hmm.cpp:18-167.
+ *   nstates must be 3 (else ED_ERR_INVALID; the reference prints and returns a C NULL, :37-40)
+ *   transitions[9]        3x3 column-major (:25)
+ *   probabilities[3*nobs] nobs x 3 column-major in HMM order normal, deletion, duplication (:26)
+ *   positions[nobs], expected_length (:29-30)
+ *   path_out[nobs]        Viterbi state per observation, as doubles like the reference's REALSXP (:139-141)
+ *   calls_out[4*calls_cap] column-major calls_cap x 4 (start.p, end.p, type, nexons), 1-based (:111-121, :145-149);
+ *                         row r of column c is calls_out[c*calls_cap + r]
+ *   n_calls               number of calls found (if > calls_cap only calls_cap rows were written) */
+int ed_hmm(int32_t nstates, int32_t nobs, const double* transitions, const double* probabilities,
+           const int32_t* positions, double expected_length, double* path_out, double* calls_out, int64_t calls_cap,
+           int64_t* n_calls);
+
+/* =====================================================================================
+ * 2. Batched interface (device-resident)
+ * ===================================================================================== */
+
+/* One CNV call.  exon indices are 0-based, inclusive, into the plan's exon order; they equal the
+ * reference's start.p-1 / end.p-1 after its dummy-exon and shift corrections
+ * (R/class_definition.R:371-372, :409-410).  type: 1 deletion, 2 duplication (src/hmm.cpp:115). */
+typedef struct {
+  int32_t sample;     /* column of the batch */
+  int32_t chrom;      /* chromosome index of the plan */
+  int32_t start_exon; /* first exon of the call */
+  int32_t end_exon;   /* last exon of the call */
+  int32_t type;
+  int32_t nexons;     /* the reference's nexons counter, quirks included (src/hmm.cpp:104-126) */
+} ed_call;
+
+typedef struct ed_plan ed_plan;
+typedef struct ed_batch ed_batch;
+
+/* A plan fixes the exon design and the HMM parameters of CallCNVs (reference R/class_definition.R:311,
+ * defaults transition.probability=1e-4, expected.CNV.length=5e4 at :261):
+ *   exons must already be ordered by (chromosome, position) as :323-336 orders them;
+ *   chrom_off[n_chrom+1] delimits the chromosomes (chains, :354); start/end are the exon coordinates.
+ * Creating the plan builds, on the host with libm exactly as src/hmm.cpp:62-79 does, the
+ * distance-dependent log-transition table of every exon gap (9 doubles per gap, shared by all
+ * samples) and uploads it. */
+int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_t n_chrom, const int32_t* chrom_off,
+                   const int32_t* start, const int32_t* end, double transition_probability,
+                   double expected_cnv_length);
+void ed_plan_destroy(ed_plan* plan);
+int64_t ed_plan_n_exons(const ed_plan* plan);
+
+/* A batch owns the device working set for n_samples samples of one plan:
+ *   log-likelihoods  double [n_exons][3][n_samples]  (deletion, normal, duplication; sample-minor)
+ *   Viterbi path     uint8  [n_exons][n_samples]     (0 normal, 1 deletion, 2 duplication)
+ *   call table       ed_call[n_calls], ordered by (sample, chromosome, position) */
+int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples);
+void ed_batch_destroy(ed_batch* batch);
+
+/* Fit the per-sample beta-binomial model  cbind(test, reference) ~ 1  (what aod::betabin does at
+ * reference R/class_definition.R:118): writes phi[n_samples] and expected[n_samples] (DEVICE pointers).
+ * d_test/d_ref: int32 [n_exons][n_samples] sample-minor DEVICE matrices. */
+int ed_batch_fit(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
+                 void* stream);
+
+/* Emissions + Viterbi + call segmentation for the whole batch.  All pointers are DEVICE pointers.
+ * d_phi/d_expected: per-sample dispersion and expected proportion (from ed_batch_fit or given).
+ * Asynchronous on `stream`; results are valid after the stream is synchronised (the accessors that
+ * return host data synchronise themselves). */
+int ed_batch_run(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
+                 const double* d_expected, double mixture, void* stream);
+
+/* device-resident results of the last ed_batch_run */
+const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples] */
+const uint8_t* ed_batch_path(const ed_batch* batch);   /* [n_exons][n_samples]    */
+const ed_call* ed_batch_calls(const ed_batch* batch);  /* device array, length ed_batch_n_calls() */
+/* synchronises the stream of the last run */
+int ed_batch_n_calls(ed_batch* batch, int64_t* n_calls);
+int ed_batch_n_gsl_errors(ed_batch* batch, int64_t* n_events);
+/* copy results to host buffers (each synchronises) */
+int ed_batch_copy_calls(ed_batch* batch, ed_call* host_calls, int64_t cap);
+int ed_batch_copy_path(ed_batch* batch, uint8_t* host_path /* [n_exons][n_samples] */);
+int ed_batch_copy_loglik(ed_batch* batch, double* host_loglik /* [n_exons][3][n_samples] */);
+
+/* Per-stage device times of the last ed_batch_run / ed_batch_fit, measured with HIP events on the
+ * stream the kernels were launched on (enable before the run; costs nothing when disabled).
+ * ms[]: 0 sample constants, 1 emissions, 2 Viterbi (forward + trace-back + call count),
+ *       3 call table (scan + fill), 4 dispersion fit.  Synchronises. */
+int ed_batch_enable_timing(ed_batch* batch, int enable);
+int ed_batch_stage_ms(ed_batch* batch, float ms[5]);
+
+/* ---- utilities ---- */
+/* device memory through the library, for callers without a HIP binding (tests, R shim) */
+int ed_malloc(void** dptr, size_t bytes);
+int ed_free(void* dptr);
+int ed_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int ed_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int ed_synchronize(void* stream);
+
+/* Element-wise evaluation of the device special functions on host arrays (used by the parity tests
+ * to compare the device arithmetic with the checker bit for bit).
+ * which: 0 lnbeta(x,y)  1 portable log(x)  2 portable exp(x)  3 sqrt(x)  4 x/y  5 portable sin(x) on [0,pi] */
+int ed_eval_sf(int which, int64_t n, const double* x, const double* y, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXOMEDEPTH_AMD_H */

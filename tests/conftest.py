@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU checker (oracle/libed_oracle.so), built on demand with gcc."""
+    from oracle import edoracle
+    edoracle.build()
+    return edoracle
+
+
+@pytest.fixture(scope="session")
+def edlib():
+    """The product library; GPU tests fail loudly if it is missing or no device is usable."""
+    import exomedepth_amd
+    from exomedepth_amd import _lib
+    L = _lib.lib()
+    assert L.ed_device_count() > 0, "no HIP device visible: GPU tests must run on the MI355X box"
+    return exomedepth_amd

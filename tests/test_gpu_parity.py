@@ -1,0 +1,222 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU checker.
+
+Bars (BASELINE.json north_star): Viterbi state paths and call tables bit-identical; log-likelihoods
+within 1e-10 relative of the reference's arithmetic (the libm flavour of the checker, itself pinned
+bit-for-bit to the reference's compiled special functions) -- and, stronger, bit-identical to the
+checker's portable flavour, which evaluates the same log/exp definitions as the device.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-10  # north_star tolerance on log-likelihoods
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def eval_sf(ed, which, x, y=None):
+    import ctypes as C
+    from exomedepth_amd._lib import check, lib
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yp = C.c_void_p(y.ctypes.data)
+    check(lib().ed_eval_sf(which, x.size, C.c_void_p(x.ctypes.data), yp, C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def test_ieee_div_sqrt_bit_exact(edlib):
+    """The contract rests on / and sqrt being correctly rounded on gfx950 as on x86-64."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    x = np.exp(rng.uniform(-40, 40, n)) * rng.choice([-1.0, 1.0], n)
+    y = np.exp(rng.uniform(-40, 40, n))
+    assert np.array_equal(bits(eval_sf(edlib, 4, x, y)), bits(x / y))
+    assert np.array_equal(bits(eval_sf(edlib, 3, np.abs(x))), bits(np.sqrt(np.abs(x))))
+    # narrow mantissa patterns / exact quotients / subnormal results
+    a = rng.integers(1, 1 << 20, n).astype(np.float64)
+    b = rng.integers(1, 1 << 20, n).astype(np.float64)
+    assert np.array_equal(bits(eval_sf(edlib, 4, a, b)), bits(a / b))
+    tiny = np.exp(rng.uniform(-745, -650, 4096))
+    assert np.array_equal(bits(eval_sf(edlib, 4, tiny, np.full(4096, 3.0))), bits(tiny / 3.0))
+
+
+def test_portable_log_exp_sin_bit_exact(edlib, oracle):
+    rng = np.random.default_rng(12)
+    n = 1 << 20
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, n)), rng.uniform(0.5, 2.0, n), [0.0, -1.0, np.inf, np.nan, 5e-324, 1.0]])
+    assert np.array_equal(bits(eval_sf(edlib, 1, x)), bits(oracle.plog(x)))
+    xe = np.concatenate([rng.uniform(-750, 715, n), rng.uniform(-1, 1, n), [np.nan, 0.0, -746.0, 710.0]])
+    assert np.array_equal(bits(eval_sf(edlib, 2, xe)), bits(oracle.pexp(xe)))
+    xs = rng.uniform(0, np.pi, n)
+    assert np.array_equal(bits(eval_sf(edlib, 5, xs)), bits(oracle.psin(xs)))
+
+
+def test_lnbeta_bit_exact_wide_grid(edlib, oracle):
+    rng = np.random.default_rng(13)
+    n = 1 << 20
+    x = np.exp(rng.uniform(np.log(1e-3), np.log(1e7), n))
+    y = np.exp(rng.uniform(np.log(1e-3), np.log(1e7), n))
+    got = eval_sf(edlib, 0, x, y)
+    assert np.array_equal(bits(got), bits(oracle.lnbeta(x, y, oracle.PORTABLE)))
+    ref = oracle.lnbeta(x, y, oracle.LIBM)
+    # away from the zero crossing of log B the relative bar applies directly; near it, absolute
+    big = np.abs(ref) > 1e-3
+    assert np.max(np.abs(got[big] - ref[big]) / np.abs(ref[big])) < REL_TOL
+    assert np.max(np.abs(got[~big] - ref[~big])) < 1e-13 if np.any(~big) else True
+
+
+def test_lnbeta_seams_and_specials(edlib, oracle):
+    seams = np.array([0.0199, 0.02, 0.0201, 0.49, 0.5, 0.51, 0.99, 0.9901, 1.0, 1.0099, 1.01, 1.99, 2.0, 2.0099,
+                      2.01, 9.99, 10.0, 10.01, 8191.9, 8192.0, 8192.1, 4.5e15, 4.6e15, 1e16, 1e300])
+    X, Y = np.meshgrid(seams, seams)
+    x, y = X.ravel(), Y.ravel()
+    assert np.array_equal(bits(eval_sf(edlib, 0, x, y)), bits(oracle.lnbeta(x, y, oracle.PORTABLE)))
+    # ratio seam min/max = 0.2
+    base = np.exp(np.random.default_rng(3).uniform(-3, 12, 4096))
+    for r in (0.2, np.nextafter(0.2, 0), np.nextafter(0.2, 1), 0.19999, 0.20001):
+        assert np.array_equal(bits(eval_sf(edlib, 0, base * r, base)), bits(oracle.lnbeta(base * r, base, oracle.PORTABLE)))
+    # specials: zero, NaN, inf
+    sx = np.array([0.0, 3.0, np.nan, np.nan, 5.0, np.inf, np.inf, 2.0])
+    sy = np.array([3.0, 0.0, np.nan, 5.0, np.nan, 4.0, np.inf, np.inf])
+    got = eval_sf(edlib, 0, sx, sy)
+    exp = oracle.lnbeta(sx, sy, oracle.PORTABLE)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert np.array_equal(bits(got[~np.isnan(got)]), bits(exp[~np.isnan(exp)]))
+
+
+def _rows(rng, n):
+    phi = rng.uniform(1e-4, 0.3, n)
+    e = rng.uniform(0.02, 0.6, n)
+    tot = rng.integers(0, 4000, n).astype(np.int32)
+    obs = np.minimum(rng.binomial(tot, e), tot).astype(np.int32)
+    return phi, e, tot, obs
+
+
+def test_get_loglike_matrix_parity(edlib, oracle):
+    rng = np.random.default_rng(21)
+    phi, e, tot, obs = _rows(rng, 200_000)
+    got = edlib.get_loglike_matrix(phi, e, tot, obs)
+    port, _ = oracle.get_loglike_matrix(phi, e, tot, obs, flavour=oracle.PORTABLE)
+    assert np.array_equal(bits(got), bits(port))
+    ref, _ = oracle.get_loglike_matrix(phi, e, tot, obs, flavour=oracle.LIBM)
+    nz = np.abs(ref) > 1e-6
+    assert np.max(np.abs(got[nz] - ref[nz]) / np.abs(ref[nz])) < REL_TOL
+    assert np.max(np.abs(got[~nz] - ref[~nz])) < 1e-12 if np.any(~nz) else True
+
+
+def test_get_loglike_matrix_edge_rows(edlib, oracle):
+    # total = 0 -> exactly [0,0,0]; obs = 0; obs = total; tiny / large phi; huge total; tiny e; mixture 0.5;
+    # e = 0 -> [0,0,0] with GSL errors; phi = 1 -> NaN row (lnbeta(0,0))
+    phi = np.array([0.005, 0.005, 0.005, 1e-9, 0.5, 0.002, 0.01, 0.005, 0.005, 1.0])
+    e = np.array([0.2, 0.2, 0.2, 0.1, 0.1, 0.12, 1e-6, 0.2, 0.0, 0.3])
+    tot = np.array([0, 500, 500, 900, 40, 2_000_000, 1000, 800, 10, 10], dtype=np.int32)
+    obs = np.array([0, 0, 500, 95, 3, 240_000, 0, 150, 3, 3], dtype=np.int32)
+    for mix in (1.0, 0.5):
+        got, nerr = edlib.get_loglike_matrix(phi, e, tot, obs, mixture=mix, return_errors=True)
+        exp, oerr = oracle.get_loglike_matrix(phi, e, tot, obs, mixture=mix, flavour=oracle.PORTABLE)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        m = ~np.isnan(exp)
+        assert np.array_equal(bits(got[m]), bits(exp[m]))
+        assert nerr == oerr
+        assert np.all(got[0] == 0.0)
+        assert np.all(got[8] == 0.0)
+        assert np.all(np.isnan(got[9]))
+    # empty input
+    assert edlib.get_loglike_matrix(np.zeros(0), np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32)).shape == (0, 3)
+
+
+def test_viterbi_known_answers(edlib):
+    """The one example with a stated expectation in the reference: R/tools.R:74-85."""
+    T = np.full((3, 3), 1 / 3)
+    ll = np.array([[0, -10, -10]] * 3 + [[-10, -10, 0]] * 3 + [[-10, 0, -10]] * 4, dtype=float)
+    res = edlib.viterbi_hmm(T, ll, np.arange(1, 11), 1)
+    assert res["Viterbi.path"].tolist() == [0, 0, 0, 2, 2, 2, 1, 1, 1, 0]   # "note the final 0 state"
+    assert [tuple(r) for r in res["calls"].tolist()] == [(4, 6, 2, 3), (4, 9, 1, 3)]
+    res = edlib.viterbi_hmm(np.eye(3), ll, np.arange(1, 11), 1)              # "no call is made"
+    assert res["Viterbi.path"].tolist() == [0] * 10 and len(res["calls"]) == 0
+    with pytest.raises(ValueError):
+        edlib.viterbi_hmm(np.ones((3, 2)), ll, np.arange(1, 11), 1)
+    with pytest.raises(ValueError):
+        edlib.viterbi_hmm(T, ll, np.arange(1, 10), 1)
+    from exomedepth_amd import EdError
+    with pytest.raises(EdError):   # nstates != 3: the reference prints and returns NULL
+        edlib.viterbi_hmm(np.full((2, 2), .5), ll[:, :2], np.arange(1, 11), 1)
+
+
+def test_viterbi_random_chains_bit_exact(edlib, oracle):
+    rng = np.random.default_rng(31)
+    t = 1e-4
+    T = np.array([[1 - t, t / 2, t / 2], [.5, .5, 0], [.5, 0, .5]])
+    for nobs in (2, 3, 17, 1000, 20001):
+        ll = rng.normal(-3, 2, (nobs, 3))
+        ll[rng.random(nobs) < 0.02, 1] = -np.inf
+        ll[rng.random(nobs) < 0.01] = 0.0
+        pos = np.cumsum(rng.integers(1, 20000, nobs)).astype(np.int32)
+        got = edlib.viterbi_hmm(T, ll, pos, 50000.0)
+        p, c = oracle.hmm(T, ll, pos, 50000.0)
+        assert np.array_equal(got["Viterbi.path"], p)
+        gc = np.stack([got["calls"][k] for k in ("start.p", "end.p", "type", "nexons")], axis=1) if len(got["calls"]) else np.zeros((0, 4))
+        assert np.array_equal(gc, c)
+
+
+def _batch_vs_oracle(edlib, oracle, E, S, C, seed, mixture=1.0):
+    from exomedepth_amd import synth
+    chrom_off, start, end = synth.exon_design(E, C, seed)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=3, mean_depth=60.0)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    batch.run(test, ref, phi, p, mixture=mixture)
+    ll = batch.loglik()
+    path = batch.path()
+    calls = batch.calls()
+    batch.close(); plan.close()
+    k = 0
+    for s in range(S):
+        exp_ll, _ = oracle.get_loglike_matrix(phi[s], p[s], (test[:, s] + ref[:, s]), test[:, s], mixture, oracle.PORTABLE)
+        assert np.array_equal(bits(ll[:, :, s]), bits(exp_ll)), "sample %d" % s
+        exp_path, exp_calls = oracle.callcnvs(exp_ll, chrom_off, start, end)
+        assert np.array_equal(path[:, s].astype(np.int8), exp_path), "sample %d" % s
+        mine = calls[calls["sample"] == s]
+        assert len(mine) == len(exp_calls)
+        assert np.array_equal(mine["start_exon"] + 1, exp_calls[:, 0].astype(np.int64))
+        assert np.array_equal(mine["end_exon"] + 1, exp_calls[:, 1].astype(np.int64))
+        assert np.array_equal(mine["type"], exp_calls[:, 2].astype(np.int64))
+        assert np.array_equal(mine["nexons"], exp_calls[:, 3].astype(np.int64))
+        k += len(mine)
+    assert k == len(calls)
+    # the call table is ordered by (sample, chromosome, position)
+    key = calls["sample"].astype(np.int64) * (E + 1) + calls["start_exon"]
+    assert np.all(np.diff(key) >= 0)
+    return len(calls)
+
+
+def test_batch_pipeline_parity_small(edlib, oracle):
+    n = _batch_vs_oracle(edlib, oracle, E=3000, S=70, C=5, seed=5)   # ragged: S not a multiple of 64
+    assert n > 0
+
+
+def test_batch_pipeline_parity_tumor_mixture_and_tiny(edlib, oracle):
+    _batch_vs_oracle(edlib, oracle, E=400, S=3, C=24, seed=6, mixture=0.6)
+    _batch_vs_oracle(edlib, oracle, E=64, S=1, C=1, seed=7)
+
+
+def test_batch_empty_chromosomes(edlib, oracle):
+    from exomedepth_amd import synth
+    chrom_off = np.array([0, 0, 500, 500, 900], dtype=np.int32)   # chromosomes 0 and 2 are empty
+    _, start, end = synth.exon_design(900, 1, 9)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, 5, 9, n_segments=2, mean_depth=80.0)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, 5)
+    batch.run(test, ref, phi, p)
+    path = batch.path()
+    for s in range(5):
+        ll, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.PORTABLE)
+        ep, ec = oracle.callcnvs(ll, chrom_off, start, end)
+        assert np.array_equal(path[:, s].astype(np.int8), ep)
+    batch.close(); plan.close()
