@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the hot path on MI355X, with roofline and CPU-baseline legs.
+
+A "step" is one pass of the hot path over one batch of synthetic counts that are already resident
+in HBM: per-sample constants -> beta-binomial emissions for every (exon, sample) cell -> Viterbi per
+(sample, chromosome) chain -> call table (+ the per-sample dispersion fit when --fit).  Workload:
+BASELINE.json configs[2] geometry, 200 000 exons x 1024 samples per GPU (weak scaling: N GPUs hold
+N x 1024 samples, configs[3] at N=8).  Metric: exons*samples/s (BASELINE.json.metric).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched with
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VALU_PEAK_TFLOPS = 78.6   # FP64 vector peak (no MFMA applies to this path)
+ALGO_BYTES_PER_CELL = 9        # read test 4 B + read reference 4 B + write state 1 B
+
+
+def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end):
+    """The CPU checker's libm flavour (bit-identical to the reference's compiled special functions)
+    timed on one host core over a bounded sample of the same workload."""
+    from oracle import edoracle as eo
+
+    eo.build()
+    n_s = test_h.shape[1]
+    t_emit = t_vit = 0.0
+    for s in range(n_s):
+        t0 = time.perf_counter()
+        ll, _ = eo.get_loglike_matrix(phi[s], p[s], test_h[:, s] + ref_h[:, s], test_h[:, s], 1.0, eo.LIBM)
+        t1 = time.perf_counter()
+        eo.callcnvs(ll, chrom_off, start, end)
+        t2 = time.perf_counter()
+        t_emit += t1 - t0
+        t_vit += t2 - t1
+    cells = test_h.shape[0] * n_s
+    return {"value": cells / (t_emit + t_vit), "unit": "exons*samples/s", "cores": 1, "kind": "port",
+            "sample": "%d samples x %d exons of the same synthetic batch, emissions + Viterbi + call table, "
+                      "oracle libm flavour (bit-identical to the reference's compiled lnbeta), single thread"
+                      % (n_s, test_h.shape[0]),
+            "emissions_s": t_emit, "viterbi_s": t_vit}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--exons", type=int, default=200_000)
+    ap.add_argument("--samples", type=int, default=1024, help="samples per GPU")
+    ap.add_argument("--chroms", type=int, default=24)
+    ap.add_argument("--fit", type=int, default=0, help="1: include the per-sample dispersion fit in the step")
+    ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
+                  % (args.gpus, world), file=sys.stderr)
+        if args.gpus > 1 and world == 1:
+            sys.exit(2)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import exomedepth_amd as ed
+    from exomedepth_amd import dist as eddist
+    from exomedepth_amd import synth
+
+    E, S, C = args.exons, args.samples, args.chroms
+    chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
+    torch.manual_seed(20250620 + 3 + rank)
+    test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=20250620 + 3 + 1000 * rank)
+    torch.cuda.synchronize()
+
+    plan = ed.Plan(chrom_off, start, end, 1e-4, 50000.0, device=local_rank)
+    batch = ed.Batch(plan, S)
+    batch.enable_timing(True)
+    stream = torch.cuda.current_stream().cuda_stream
+    phi_fit = torch.empty(S, dtype=torch.float64, device=dev)
+    p_fit = torch.empty(S, dtype=torch.float64, device=dev)
+
+    def step():
+        if args.fit:
+            batch.fit(test, ref, phi_fit, p_fit, stream=stream)
+            batch.run(test, ref, phi_fit, p_fit, 1.0, stream=stream)
+        else:
+            batch.run(test, ref, phi, p, 1.0, stream=stream)
+
+    def finish():
+        """final gather of the compact call tables (the path's only collective)"""
+        calls = batch.calls()
+        if world > 1:
+            t = eddist.calls_to_tensor(calls, dev)
+            g = eddist.gather_call_tables(t, rank * S)
+            return int(g.shape[0]) if g is not None else 0
+        return len(calls)
+
+    for _ in range(args.warmup):
+        step()
+    finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ms = batch.stage_ms()   # reads the HIP events of this step (synchronises the stream)
+        for k, v in ms.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    n_calls = finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    cells_per_step = E * S * world
+    value = cells_per_step * args.steps / elapsed
+    stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+
+    if rank == 0:
+        t_emit = stage_ms["emissions"] * 1e-3
+        achieved = ALGO_BYTES_PER_CELL * E * S / t_emit / 1e9 if t_emit > 0 else 0.0
+        out = {
+            "metric": "exons*samples/s through betabinom emissions + Viterbi" + (" + dispersion fit" if args.fit else ""),
+            "value": value, "unit": "exons*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
+                                   "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
+                                   % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit),
+                       "parallelism": "samples sharded, %d rank(s); call tables gathered over RCCL" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_emit_batch", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_cell": ALGO_BYTES_PER_CELL, "kernel_ms": stage_ms["emissions"],
+                         "note": "FP64-VALU/transcendental-bound path (SURVEY.md 0.5): the HBM roofline is the "
+                                 "formal denominator; cells/s of the kernel = %.4g" % (E * S / t_emit if t_emit else 0)},
+            "stage_ms": stage_ms, "n_calls": n_calls,
+        }
+        if world == 1 and args.cpu_samples > 0:
+            k = min(args.cpu_samples, S)
+            out["cpu_baseline"] = cpu_baseline(test[:, :k].cpu().numpy(), ref[:, :k].cpu().numpy(),
+                                               p[:k].cpu().numpy(), phi[:k].cpu().numpy(), chrom_off, start, end)
+            out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    batch.close()
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

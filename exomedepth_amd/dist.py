@@ -1,0 +1,56 @@
+"""Multi-GPU layout of the path: samples are independent (reference vignette loop,
+vignette/vignette.Rnw:390-431), so each rank owns a contiguous slab of sample columns and runs the
+whole pipeline locally; the exon design (plan) is replicated.  The only collective is the final
+gather of the compact call tables (KBs per rank) -- paths and likelihoods stay resident on their GPU.
+
+One process per GPU; torch.distributed with backend "nccl" (= RCCL over xGMI on ROCm).  The same
+code runs on the "gloo" backend with CPU tensors, which is how tests/test_dist_gloo.py covers it.
+"""
+import numpy as np
+
+
+def shard_bounds(n_samples, rank, world_size):
+    """Contiguous, balanced slab [lo, hi) of sample columns owned by `rank`."""
+    base, rem = divmod(int(n_samples), int(world_size))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def gather_call_tables(local_calls, sample_offset, group=None, dst=0):
+    """Gather per-rank call tables on `dst`.
+
+    local_calls: torch int32 tensor [n_local, 6] (sample, chrom, start_exon, end_exon, type, nexons)
+    on the backend's device; `sample` is local to the rank and is shifted by sample_offset so that the
+    gathered table indexes the global sample axis.  Returns the concatenated [n_total, 6] tensor on
+    `dst` (ordered by rank, hence by global sample) and None elsewhere.  Variable lengths are handled
+    by one all_gather of the counts followed by one padded all_gather of the rows."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local_calls.device
+    rows = local_calls.clone()
+    if rows.numel():
+        rows[:, 0] += int(sample_offset)
+    n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap, 6), dtype=torch.int32, device=dev)
+    padded[: rows.shape[0]] = rows
+    bufs = [torch.zeros((cap, 6), dtype=torch.int32, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def calls_to_tensor(calls_np, device):
+    """Structured numpy call table (api.CALL_DTYPE) -> int32 [n,6] torch tensor on `device`."""
+    import torch
+
+    a = np.ascontiguousarray(calls_np).view(np.int32).reshape(-1, 6)
+    return torch.from_numpy(a.copy()).to(device)
