@@ -1,0 +1,71 @@
+// ed_fit_dev.hpp -- device arithmetic of the per-sample beta-binomial fit (kernel group K5).
+//
+// The reference fits  cbind(test, reference) ~ 1  with aod::betabin (reference R/class_definition.R:118),
+// a third-party package that is not in the reference tree: it maximises, by Nelder-Mead,
+//     l(p, phi) = sum_e [ lchoose(n_e, y_e) + lbeta(a + y_e, b + n_e - y_e) - lbeta(a, b) ],
+//     a = p (1 - phi)/phi,  b = (1 - p)(1 - phi)/phi.
+// This file is a NEW algorithm for the same maximum-likelihood estimate: Newton's method on
+// (eta, lambda) = (logit p, log(a + b)) with the exact gradient and Hessian, which need the digamma
+// and trigamma functions at a + y, b + n - y and a + b + n for every exon.  Nothing here has a
+// bit-level counterpart in the reference; the checker (oracle/) holds an independent CPU fit and the
+// in-tree digamma/trigamma of the reference (src/VP_psi.c:409-485, :744-787) to compare against.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ed_pmath.h"
+
+namespace edfit {
+
+// psi(x) and psi'(x) for x > 0: upward recurrence to x >= 10, then the asymptotic (Stirling) series
+// with 7 Bernoulli terms (truncation < 2e-16 relative at x = 10).
+__device__ __forceinline__ void digamma_trigamma(double x, double& psi, double& psi1)
+{
+  double s0 = 0.0, s1 = 0.0;
+  while (x < 10.0) {   // divergent only for small shape parameters (high dispersion, low counts)
+    const double r = 1.0 / x;
+    s0 += r;
+    s1 = __builtin_fma(r, r, s1);
+    x += 1.0;
+  }
+  const double r = 1.0 / x;
+  const double w = r * r;
+  // psi(x)  = ln x - 1/(2x) - sum_k B_2k / (2k x^2k)
+  double p = 1.0 / 12.0;                       // B14/14
+  p = __builtin_fma(p, w, -691.0 / 32760.0);   // B12/12
+  p = __builtin_fma(p, w, 1.0 / 132.0);        // B10/10
+  p = __builtin_fma(p, w, -1.0 / 240.0);       // B8/8
+  p = __builtin_fma(p, w, 1.0 / 252.0);        // B6/6
+  p = __builtin_fma(p, w, -1.0 / 120.0);       // B4/4
+  p = __builtin_fma(p, w, 1.0 / 12.0);         // B2/2
+  psi = (ed_plog(x) - 0.5 * r) - p * w - s0;
+  // psi'(x) = 1/x + 1/(2x^2) + sum_k B_2k / x^(2k+1)
+  double q = 7.0 / 6.0;                        // B14
+  q = __builtin_fma(q, w, -691.0 / 2730.0);    // B12
+  q = __builtin_fma(q, w, 5.0 / 66.0);         // B10
+  q = __builtin_fma(q, w, -1.0 / 30.0);        // B8
+  q = __builtin_fma(q, w, 1.0 / 42.0);         // B6
+  q = __builtin_fma(q, w, -1.0 / 30.0);        // B4
+  q = __builtin_fma(q, w, 1.0 / 6.0);          // B2
+  psi1 = __builtin_fma(q * w, r, __builtin_fma(0.5, w, r)) + s1;
+}
+
+// accumulators of one sample: gradient and Hessian of the log-likelihood with respect to (a, b),
+// without the per-sample constant terms (those are added once per sample in the update kernel)
+struct Acc {
+  double ga, gb, haa, hab, hbb;
+};
+
+__device__ __forceinline__ void accumulate_cell(Acc& acc, double a, double b, double th, int y, int n)
+{
+  if (n <= 0) return;   // lbeta(a+0, b+0) - lbeta(a, b) = 0: the cell carries no information
+  double p1, q1, p2, q2, p3, q3;
+  digamma_trigamma(a + (double)y, p1, q1);
+  digamma_trigamma(b + (double)(n - y), p2, q2);
+  digamma_trigamma(th + (double)n, p3, q3);
+  acc.ga += p1 - p3;
+  acc.gb += p2 - p3;
+  acc.haa += q1 - q3;
+  acc.hab -= q3;
+  acc.hbb += q2 - q3;
+}
+
+}  // namespace edfit

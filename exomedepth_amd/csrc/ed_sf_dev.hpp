@@ -221,31 +221,42 @@ __device__ __noinline__ double lnbeta_cold(double x, double y, int* flag)
   return (lgx + lgy) - lgxy;
 }
 
-// log B(x,y) with the reference's branch selection (src/beta.c:62-113).  For x,y > 0 both the ratio
-// branch (min/max < 0.2: Gamma* form) and the general branch (three log-Gammas) are value-exact.
+// The two value-exact evaluation routes of log B for x,y > 0 (src/beta.c:62-113), split so that a
+// kernel can bin its tasks by route and run each route in branch-uniform waves:
+//   ratio route   min/max < 0.2 : Gamma* form (:69-97).  Only symmetric expressions of (x,y) occur
+//                 (gsx*gsy, x+y), so the route takes (mn, mx, rat) and needs no memory of the order.
+//   general route otherwise     : lgamma(x) + lgamma(y) - lgamma(x+y) (:101-112), again symmetric.
+__device__ __forceinline__ double lnbeta_ratio(double mn, double mx, double rat)
+{
+  const double gsa = gammastar_pos(mn);
+  const double gsb = gammastar_pos(mx);
+  const double gsxy = gammastar_pos(mn + mx);
+  const double lnopr = log1plusx_ratio(rat);
+  const double lnpre = ed_plog(((gsa * gsb) / gsxy * EDSF_M_SQRT2) * EDSF_M_SQRTPI);
+  const double t1 = mn * ed_plog(rat);
+  const double t2 = 0.5 * ed_plog(mn);
+  const double t3 = ((mn + mx) - 0.5) * lnopr;
+  return lnpre + ((t1 - t2) - t3);
+}
+
+// +inf arguments reach this route with rat = NaN; the arithmetic then yields NaN as the reference's does.
+__device__ __forceinline__ double lnbeta_general(double x, double y)
+{
+  const double lgx = lngamma_pos(x, false);
+  const double lgy = lngamma_pos(y, false);
+  const double lgxy = lngamma_pos(x + y, false);
+  return (lgx + lgy) - lgxy;
+}
+
+// log B(x,y) with the reference's branch selection (src/beta.c:62-113).
 __device__ __forceinline__ double lnbeta(double x, double y, int* flag)
 {
   if (!(x > 0.0 && y > 0.0)) return lnbeta_cold(x, y, flag);
   const double mx = (x > y ? x : y);
   const double mn = (x < y ? x : y);
   const double rat = mn / mx;
-  if (rat < 0.2) {
-    const double gsx = gammastar_pos(x);
-    const double gsy = gammastar_pos(y);
-    const double gsxy = gammastar_pos(x + y);
-    const double lnopr = log1plusx_ratio(rat);
-    const double lnpre = ed_plog(((gsx * gsy) / gsxy * EDSF_M_SQRT2) * EDSF_M_SQRTPI);
-    const double t1 = mn * ed_plog(rat);
-    const double t2 = 0.5 * ed_plog(mn);
-    const double t3 = ((x + y) - 0.5) * lnopr;
-    return lnpre + ((t1 - t2) - t3);
-  }
-  // +inf arguments reach this point with rat = NaN; the arithmetic below then yields NaN as the
-  // reference's does.
-  const double lgx = lngamma_pos(x, false);
-  const double lgy = lngamma_pos(y, false);
-  const double lgxy = lngamma_pos(x + y, false);
-  return (lgx + lgy) - lgxy;
+  if (rat < 0.2) return lnbeta_ratio(mn, mx, rat);
+  return lnbeta_general(x, y);
 }
 
 }  // namespace edsf

@@ -24,6 +24,7 @@
 
 #include "../../include/exomedepth_amd.h"
 #include "ed_sf_dev.hpp"
+#include "ed_fit_dev.hpp"
 
 #define ED_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -108,31 +109,112 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
   }
 }
 
-// one thread per (exon, sample) cell; cells are numbered exon-major / sample-minor so that a wave
-// reads 64 consecutive samples of one exon (coalesced) and writes three coalesced rows.
+// Emissions for the batch.  Each (cell, state) pair is one log-Beta *task*; a task takes one of two
+// value-exact routes (ratio / general, see ed_sf_dev.hpp) that differ ~1.5x in cost and that adjacent
+// cells pick differently (the selector is min/max < 0.2 of the shape parameters, src/beta.c:64-69).
+// Left to the exec mask, nearly every wave would execute both routes.  Instead the workgroup bins its
+// kEmitCells*3*kEmitBlock tasks through LDS: ratio-route tasks are packed from the front of the task
+// array, all others from the back, so every wave of the evaluation phase but at most one runs a
+// single route.  Cells are numbered exon-major / sample-minor: a wave reads 64 consecutive samples of
+// one exon (coalesced) and writes three coalesced rows of the [E][3][S] likelihood matrix.
+constexpr int kEmitCells = 2;                                // cells per thread
+constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per workgroup
+
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
              const int* __restrict__ cflags, int64_t E, int64_t S, double* __restrict__ loglik,
              unsigned long long* __restrict__ nerr)
 {
-  const int64_t cell = (int64_t)blockIdx.x * kEmitBlock + threadIdx.x;
-  if (cell >= E * S) return;
-  const int64_t e = cell / S;
-  const int64_t s = cell - e * S;
-  const int32_t obs = test[cell];
-  const int32_t tot = obs + ref[cell];   // as.integer(reference + test), R/class_definition.R:187
+  __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
+  __shared__ double t_b[kEmitTasks];   // max (ratio route) or y
+  __shared__ double t_r[kEmitTasks];   // min/max
+  __shared__ int n_front, n_back;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  if (tid == 0) { n_front = 0; n_back = 0; }
+  __syncthreads();
+  const int64_t ncell = E * S;
+  const int64_t cell0 = (int64_t)blockIdx.x * (kEmitBlock * kEmitCells) + tid;
+  int slot[kEmitCells * 3];
   int nflag = 0;
+  // ---- phase 1: classify and scatter the tasks ----
 #pragma unroll
-  for (int st = 0; st < 3; ++st) {
-    const double a1 = consts[(st * 3 + 0) * S + s];
-    const double a2 = consts[(st * 3 + 1) * S + s];
-    const double c = consts[(st * 3 + 2) * S + s];
-    int flag = 0;
-    const double x = a1 + (double)obs;
-    const double y = (a2 + (double)tot) - (double)obs;
-    const double v = edsf::lnbeta(x, y, &flag) - c;
-    loglik[(e * 3 + st) * S + s] = v;
-    nflag += flag + cflags[st * S + s];
+  for (int k = 0; k < kEmitCells; ++k) {
+    const int64_t cell = cell0 + (int64_t)k * kEmitBlock;
+    const bool live = cell < ncell;
+    int32_t obs = 0, tot = 0;
+    int64_t s = 0;
+    if (live) {
+      obs = test[cell];
+      tot = obs + ref[cell];   // as.integer(reference + test), R/class_definition.R:187
+      s = cell % S;
+    }
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      double x = 1.0, y = 1.0;
+      if (live) {
+        const double a1 = consts[(st * 3 + 0) * S + s];
+        const double a2 = consts[(st * 3 + 1) * S + s];
+        x = a1 + (double)obs;                       // src/CNV_estimate.cpp:49
+        y = (a2 + (double)tot) - (double)obs;
+        nflag += cflags[st * S + s];
+      }
+      const bool pos = (x > 0.0 && y > 0.0);
+      const double mx = (x > y ? x : y);
+      const double mn = (x < y ? x : y);
+      const double rat = mn / mx;
+      const bool front = live && pos && (rat < 0.2);
+      const bool back = live && !front;
+      // wave-aggregated slot allocation
+      const unsigned long long mf = __ballot(front), mb = __ballot(back);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      int basef = 0, baseb = 0;
+      if (lane == 0) {
+        basef = atomicAdd(&n_front, __popcll(mf));
+        baseb = atomicAdd(&n_back, __popcll(mb));
+      }
+      basef = __shfl(basef, 0, 64);
+      baseb = __shfl(baseb, 0, 64);
+      int sl = -1;
+      if (front) {
+        sl = basef + __popcll(mf & below);
+        t_a[sl] = mn; t_b[sl] = mx; t_r[sl] = rat;
+      } else if (back) {
+        sl = kEmitTasks - 1 - (baseb + __popcll(mb & below));
+        t_a[sl] = x; t_b[sl] = y; t_r[sl] = rat;
+      }
+      slot[k * 3 + st] = sl;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: evaluate; slots [0,nf) take the ratio route, slots [kEmitTasks-nb, kEmitTasks) the rest ----
+  const int nf = n_front, nb = n_back;
+#pragma unroll 1
+  for (int r = 0; r < kEmitCells * 3; ++r) {
+    const int sl = r * kEmitBlock + tid;
+    if (sl < nf) {
+      t_a[sl] = edsf::lnbeta_ratio(t_a[sl], t_b[sl], t_r[sl]);
+    } else if (sl >= kEmitTasks - nb) {
+      const double x = t_a[sl], y = t_b[sl];
+      int flag = 0;
+      t_a[sl] = (x > 0.0 && y > 0.0) ? edsf::lnbeta_general(x, y) : edsf::lnbeta_cold(x, y, &flag);
+      nflag += flag;
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: gather, subtract the per-sample constant, store ----
+#pragma unroll
+  for (int k = 0; k < kEmitCells; ++k) {
+    const int64_t cell = cell0 + (int64_t)k * kEmitBlock;
+    if (cell < ncell) {
+      const int64_t e = cell / S;
+      const int64_t s = cell - e * S;
+#pragma unroll
+      for (int st = 0; st < 3; ++st) {
+        const double c = consts[(st * 3 + 2) * S + s];
+        loglik[(e * 3 + st) * S + s] = t_a[slot[k * 3 + st]] - c;
+      }
+    }
   }
   if (nflag) atomicAdd(nerr, (unsigned long long)nflag);
 }
@@ -221,16 +303,53 @@ __device__ __forceinline__ int summarise_chain(int64_t last, TB tb, EMIT emit)
   return ncalls;
 }
 
-// Batched chains.  Block = one wave; lane = sample; blockIdx.y = chromosome.
-//   loglik [E][3][S] in S4 column order (deletion, normal, duplication): HMM state j reads column {1,0,2}[j]
-//   lt     [(E + C)][9]: gap g = lo + c + (i-1) for padded step i = 1..m+1 of chromosome c (lo = chrom_off[c])
-//   path   [E][S]: holds the packed back-pointers during the forward pass, the Viterbi state afterwards
+// ---- batched chains -------------------------------------------------------------------------
+// Block = one wave; lane = sample; blockIdx.y = chromosome.  A chain is strictly sequential (the
+// max-plus recurrence is evaluated in the reference's association order, so no scan), which makes the
+// kernel latency-bound: what matters is how many loads each wave keeps in flight.
+//   loglik [E][3][S]  S4 column order (deletion, normal, duplication): HMM state j reads column {1,0,2}[j].
+//                     Emissions are fetched a whole tile of kVitTile steps ahead (register double buffer).
+//   lt3    [(E+C)][3] the three distance-dependent log-transitions of CallCNVs' matrix per exon gap
+//                     (A = into normal from a CNV state, B = staying in a CNV state, C = switching CNV
+//                     state); the two constants c0 = log(1-t), c1 = log(t/2) are kernel arguments.
+//                     gap index of padded step i of chromosome c: lo + c + (i-1).  Wave-uniform -> scalar loads.
+//   bp64   [tiles][S] back-pointers, 8 steps x 6 bits per word, one coalesced 8-byte store per 8 steps
+//   path   [E][S]     Viterbi state per exon, written by the trace-back
 // The two dummy observations of CallCNVs (R/class_definition.R:364) are implicit: the chain starts
 // from (0,-inf,-inf) (src/hmm.cpp:48-52; the first dummy row is never read) and ends with one extra
 // step whose emissions are (-100, 0, -100).
+constexpr int kVitTile = 16;  // emission prefetch tile (steps); a multiple of 8
+
+// One forward step for CallCNVs' transition matrix (src/hmm.cpp:68-88 with R/class_definition.R:343-347):
+// lt[j][k]: j=0: (c0, A, A); j=1: (c1, B, C); j=2: (c1, C, B).  Candidate order k=0,1,2 and the strict
+// '>' reproduce the reference's tie-breaking; a state no candidate improves on points to 0.
+__device__ __forceinline__ unsigned vit_step3(double& v0, double& v1, double& v2, double e0, double e1, double e2,
+                                              double c0, double c1, double A, double B, double C)
+{
+  const double NI = -HUGE_VAL;
+  double b0 = NI, b1 = NI, b2 = NI;
+  unsigned f0 = 0, f1 = 0, f2 = 0;
+  double cand;
+  cand = (e0 + v0) + c0; if (cand > b0) { b0 = cand; f0 = 0; }
+  cand = (e0 + v1) + A;  if (cand > b0) { b0 = cand; f0 = 1; }
+  cand = (e0 + v2) + A;  if (cand > b0) { b0 = cand; f0 = 2; }
+  cand = (e1 + v0) + c1; if (cand > b1) { b1 = cand; f1 = 0; }
+  cand = (e1 + v1) + B;  if (cand > b1) { b1 = cand; f1 = 1; }
+  cand = (e1 + v2) + C;  if (cand > b1) { b1 = cand; f1 = 2; }
+  cand = (e2 + v0) + c1; if (cand > b2) { b2 = cand; f2 = 0; }
+  cand = (e2 + v1) + C;  if (cand > b2) { b2 = cand; f2 = 1; }
+  cand = (e2 + v2) + B;  if (cand > b2) { b2 = cand; f2 = 2; }
+  if (e0 == NI) f0 = 0;
+  if (e1 == NI) f1 = 0;
+  if (e2 == NI) f2 = 0;
+  v0 = b0; v1 = b1; v2 = b2;
+  return f0 | (f1 << 2) | (f2 << 4);
+}
+
 __global__ void __launch_bounds__(kWave)
-k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt, const int32_t* __restrict__ chrom_off,
-          int64_t S, int32_t C, uint8_t* __restrict__ path, int32_t* __restrict__ counts)
+k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt3, double c0, double c1,
+          const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ tile_off, int64_t S, int32_t C,
+          uint64_t* __restrict__ bp64, uint8_t* __restrict__ path, int32_t* __restrict__ counts)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
   const int c = blockIdx.y;
@@ -241,42 +360,81 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt, cons
     counts[s * C + c] = 0;
     return;
   }
-  const double* __restrict__ ltc = lt + (lo + c) * 9;
-  double v[3] = {0., -HUGE_VAL, -HUGE_VAL};
-  // forward pass with a one-step-ahead prefetch of the emissions
-  double en[3];
-  {
-    const double* p = loglik + (lo * 3) * S + s;
-    en[0] = p[S]; en[1] = p[0]; en[2] = p[2 * S];
-  }
-  for (int64_t i = 0; i < m; ++i) {
-    double e[3] = {en[0], en[1], en[2]};
-    if (i + 1 < m) {
-      const double* p = loglik + ((lo + i + 1) * 3) * S + s;
-      en[0] = p[S]; en[1] = p[0]; en[2] = p[2 * S];
+  const double* __restrict__ em = loglik + (lo * 3) * S + s;   // step i, column col: em[(i*3+col)*S]
+  const double* __restrict__ l3 = lt3 + (lo + c) * 3;
+  uint64_t* __restrict__ bpc = bp64 + tile_off[c] * S + s;      // word w of this chain: bpc[w*S]
+  uint8_t* __restrict__ pth = path + lo * S + s;                // exon i of this chain: pth[i*S]
+  double v0 = 0., v1 = -HUGE_VAL, v2 = -HUGE_VAL;
+
+  // ---- forward pass ----
+  double cur[kVitTile][3], nxt[kVitTile][3];
+  auto load_tile = [&](double (&t)[kVitTile][3], int64_t base) {
+#pragma unroll
+    for (int k = 0; k < kVitTile; ++k) {
+      const int64_t i = base + k;
+      if (i < m) {
+        const double* q = em + (i * 3) * S;
+        t[k][0] = q[S]; t[k][1] = q[0]; t[k][2] = q[2 * S];
+      } else {
+        t[k][0] = 0.; t[k][1] = 0.; t[k][2] = 0.;
+      }
     }
-    const unsigned bp = vit_step(v, e, ltc + i * 9);
-    path[(lo + i) * S + s] = (uint8_t)bp;
+  };
+  load_tile(cur, 0);
+  for (int64_t base = 0; base < m; base += kVitTile) {
+    if (base + kVitTile < m) load_tile(nxt, base + kVitTile);
+#pragma unroll
+    for (int h = 0; h < kVitTile / 8; ++h) {
+      uint64_t w = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t i = base + h * 8 + k;
+        if (i < m) {
+          const unsigned bp = vit_step3(v0, v1, v2, cur[h * 8 + k][0], cur[h * 8 + k][1], cur[h * 8 + k][2], c0, c1,
+                                        l3[i * 3 + 0], l3[i * 3 + 1], l3[i * 3 + 2]);
+          w |= (uint64_t)bp << (6 * k);
+        }
+      }
+      if (base + h * 8 < m) bpc[((base >> 3) + h) * S] = w;
+    }
+#pragma unroll
+    for (int k = 0; k < kVitTile; ++k) { cur[k][0] = nxt[k][0]; cur[k][1] = nxt[k][1]; cur[k][2] = nxt[k][2]; }
   }
   // dummy last observation: only the back-pointer of state 0 is ever used (src/hmm.cpp:96)
-  int cur;
+  int st;
   {
-    const double e[3] = {-100., 0., -100.};
-    const unsigned bp = vit_step(v, e, ltc + m * 9);
-    cur = bp & 3;
+    const unsigned bp = vit_step3(v0, v1, v2, -100., 0., -100., c0, c1, l3[m * 3 + 0], l3[m * 3 + 1], l3[m * 3 + 2]);
+    st = bp & 3;
   }
-  // trace back (src/hmm.cpp:95-100), overwriting the back-pointers with the states
-  for (int64_t i = m - 1; i >= 0; --i) {
-    const int64_t a = (lo + i) * S + s;
-    const unsigned bp = path[a];
-    path[a] = (uint8_t)cur;
-    cur = (bp >> (2 * cur)) & 3;
+  // ---- trace back (src/hmm.cpp:95-100) + call count ----
+  // A call is pushed by the reference's summary loop (src/hmm.cpp:109-121) exactly where a run of a
+  // non-zero state ends, so the count is the number of positions q with tb[q] != tb[q+1], tb[q] != 0.
+  const int64_t nw = (m + 7) >> 3;
+  int count = 0, after = 0;   // after = state of the observation following the current one
+  constexpr int kDepth = 4;   // back-pointer words kept in flight
+  uint64_t ring[kDepth];
+#pragma unroll
+  for (int d = 0; d < kDepth; ++d) ring[d] = (nw - 1 - d >= 0) ? bpc[(nw - 1 - d) * S] : 0;
+  for (int64_t wb = nw - 1; wb >= 0; wb -= kDepth) {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) {
+      const int64_t wi = wb - d;
+      if (wi < 0) break;
+      const uint64_t w = ring[d];
+      if (wi - kDepth >= 0) ring[d] = bpc[(wi - kDepth) * S];
+#pragma unroll
+      for (int k = 7; k >= 0; --k) {
+        const int64_t i = wi * 8 + k;
+        if (i < m) {
+          pth[i * S] = (uint8_t)st;
+          count += (st != after && st != 0) ? 1 : 0;
+          after = st;
+          st = (int)((w >> (6 * k + 2 * st)) & 3);
+        }
+      }
+    }
   }
-  const int tb0 = cur;  // state of the first dummy observation
-  // count the calls
-  auto tb = [&](int64_t i) -> int { return i == 0 ? tb0 : (i == m + 1 ? 0 : (int)path[(lo + i - 1) * S + s]); };
-  auto nop = [](int64_t, int64_t, int, int, int) {};
-  counts[s * C + c] = summarise_chain(m + 1, tb, nop);
+  counts[s * C + c] = count;
 }
 
 // exclusive scan of n int32 counts by one workgroup; total written to *total
@@ -310,9 +468,16 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict_
   if (tid == 0) *total = carry;
 }
 
+// Call records of every chain (src/hmm.cpp:104-126 + R/class_definition.R:371-372, :409-410).  The
+// reference's summary loop, restated on exon indices x = 0..m (x = m is the dummy last observation,
+// state 0): when the state changes after a zero, `start` is set; when it changes after a non-zero
+// state a call (start, x-1, state, nexons) is pushed.  Quirks kept: `start` is NOT reset when one CNV
+// state switches directly to the other (the second call inherits the first one's start), and nexons
+// restarts only at a push.  The path is read 16 exons at a time; all-zero tiles are skipped.
 __global__ void __launch_bounds__(kWave)
 k_calls_fill(const uint8_t* __restrict__ path, const int32_t* __restrict__ chrom_off, int64_t S, int32_t C,
-             const int64_t* __restrict__ offsets, ed_call* __restrict__ calls, int64_t cap)
+             const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts, ed_call* __restrict__ calls,
+             int64_t cap)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
   const int c = blockIdx.y;
@@ -320,22 +485,51 @@ k_calls_fill(const uint8_t* __restrict__ path, const int32_t* __restrict__ chrom
   const int64_t lo = chrom_off[c], hi = chrom_off[c + 1];
   const int64_t m = hi - lo;
   if (m <= 0) return;
+  const int32_t todo = counts[s * C + c];
   const int64_t off = offsets[s * C + c];
-  auto tb = [&](int64_t i) -> int { return (i == 0 || i == m + 1) ? 0 : (int)path[(lo + i - 1) * S + s]; };
-  auto emit = [&](int64_t st, int64_t en, int type, int nexons, int k) {
-    const int64_t r = off + k;
-    if (r < cap) {
-      ed_call rec;
-      rec.sample = (int32_t)s;
-      rec.chrom = c;
-      rec.start_exon = (int32_t)(lo + st - 1);
-      rec.end_exon = (int32_t)(lo + en - 1);
-      rec.type = type;
-      rec.nexons = nexons;
-      calls[r] = rec;
+  const uint8_t* __restrict__ pth = path + lo * S + s;
+  constexpr int kT = 16;
+  int64_t start = -1;
+  int nexons = 0, prev = 0, k = 0;
+  // a wave leaves the loop as soon as all of its chains have written their calls
+  for (int64_t base = 0; base <= m && __any(k < todo); base += kT) {
+    unsigned b[kT];
+    unsigned any = 0;
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      const int64_t x = base + t;
+      b[t] = (x < m) ? pth[x * S] : 0u;
+      any |= b[t];
     }
-  };
-  summarise_chain(m + 1, tb, emit);
+    if ((any | (unsigned)prev) == 0) continue;
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      const int64_t x = base + t;
+      if (x > m) break;
+      const int cur = (int)b[t];
+      if (prev != cur) {
+        if (prev == 0) {
+          start = x;
+        } else {
+          const int64_t r = off + k;
+          if (r < cap) {
+            ed_call rec;
+            rec.sample = (int32_t)s;
+            rec.chrom = c;
+            rec.start_exon = (int32_t)(lo + start);
+            rec.end_exon = (int32_t)(lo + x - 1);
+            rec.type = prev;
+            rec.nexons = nexons;
+            calls[r] = rec;
+          }
+          ++k;
+          nexons = 0;
+        }
+      }
+      if (cur != 0) ++nexons;
+      prev = cur;
+    }
+  }
 }
 
 // Single chain with caller-supplied probabilities: the reference's C_hmm signature.
@@ -372,6 +566,151 @@ __global__ void k_viterbi_single(const double* __restrict__ proba, const double*
   *ncalls_out = summarise_chain(nobs - 1, tb, emit);
 }
 
+// ---- K5: per-sample beta-binomial fit -------------------------------------------------------
+// Exon axis cut into chunks of kFitChunk exons; thread = (sample lane, sub-chunk).  Every pass writes
+// per-chunk partial sums [chunk][q][S] that the update kernel adds up in a fixed order, so the fit is
+// reproducible run to run (no floating-point atomics).
+constexpr int kFitSub = 4;          // sub-chunks (waves) per workgroup
+constexpr int kFitChunk = 1024;     // exons per workgroup
+constexpr int kFitQ = 6;            // quantities per partial
+
+// moments for the starting point: sum y, sum n, sum y^2/n, #cells with n > 0
+__global__ void __launch_bounds__(kWave * kFitSub)
+k_fit_moments(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t E, int64_t S, int stride,
+              double* __restrict__ partial)
+{
+  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const int sub = threadIdx.y;
+  const int64_t chunk = (int64_t)blockIdx.y * kFitSub + sub;
+  if (s >= S) return;
+  const int64_t e0 = (int64_t)blockIdx.y * kFitChunk + sub * (kFitChunk / kFitSub);
+  const int64_t e1 = min(e0 + kFitChunk / kFitSub, E);
+  double sy = 0, sn = 0, syy = 0, cnt = 0;
+  for (int64_t e = e0; e < e1; e += stride) {
+    const int y = test[e * S + s];
+    const int n = y + ref[e * S + s];
+    if (n > 0) {
+      sy += (double)y; sn += (double)n;
+      syy += ((double)y * (double)y) / (double)n;
+      cnt += 1.0;
+    }
+  }
+  double* o = partial + (chunk * kFitQ) * S + s;
+  o[0] = sy; o[S] = sn; o[2 * S] = syy; o[3 * S] = cnt; o[4 * S] = 0; o[5 * S] = 0;
+}
+
+// method-of-moments start: p0 = sum y / sum n; phi0 from the Pearson statistic
+//   sum_e (y - n p)^2 / (n p q) ~ cnt + phi * sum_e (n - 1)
+__global__ void k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
+                            double* __restrict__ lam, int* __restrict__ done)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  double sy = 0, sn = 0, syy = 0, cnt = 0;
+  for (int64_t c = 0; c < nchunk; ++c) {
+    const double* o = partial + (c * kFitQ) * S + s;
+    sy += o[0]; sn += o[S]; syy += o[2 * S]; cnt += o[3 * S];
+  }
+  double p = (sn > 0) ? sy / sn : 0.5;
+  p = fmin(fmax(p, 1e-6), 1.0 - 1e-6);
+  const double q = 1.0 - p;
+  const double pearson = (syy - 2.0 * p * sy + p * p * sn) / (p * q);
+  double phi = (sn - cnt > 0) ? (pearson - cnt) / (sn - cnt) : 0.01;
+  phi = fmin(fmax(phi, 1e-4), 0.3);
+  eta[s] = ed_plog(p / q);
+  lam[s] = ed_plog((1.0 - phi) / phi);
+  done[s] = (cnt < 2.0) ? 1 : 0;   // nothing to fit
+}
+
+__global__ void __launch_bounds__(kWave * kFitSub)
+k_fit_accum(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t E, int64_t S, int stride,
+            const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
+            double* __restrict__ partial)
+{
+  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const int sub = threadIdx.y;
+  const int64_t chunk = (int64_t)blockIdx.y * kFitSub + sub;
+  if (s >= S) return;
+  if (done[s]) return;
+  const double th = ed_pexp(lam[s]);
+  const double p = 1.0 / (1.0 + ed_pexp(-eta[s]));
+  const double a = th * p, b = th * (1.0 - p);
+  const int64_t e0 = (int64_t)blockIdx.y * kFitChunk + sub * (kFitChunk / kFitSub);
+  const int64_t e1 = min(e0 + kFitChunk / kFitSub, E);
+  edfit::Acc acc = {0, 0, 0, 0, 0};
+  double cnt = 0;
+  for (int64_t e = e0; e < e1; e += stride) {
+    const int y = test[e * S + s];
+    const int n = y + ref[e * S + s];
+    if (n > 0) cnt += 1.0;
+    edfit::accumulate_cell(acc, a, b, th, y, n);
+  }
+  double* o = partial + (chunk * kFitQ) * S + s;
+  o[0] = acc.ga; o[S] = acc.gb; o[2 * S] = acc.haa; o[3 * S] = acc.hab; o[4 * S] = acc.hbb; o[5 * S] = cnt;
+}
+
+// One Newton step on (eta, lambda) = (logit p, log(a+b)); steps are capped, and a non-concave local
+// model falls back to a scaled gradient step.  `final_pass` marks passes over all exons: only those
+// may declare convergence.
+__global__ void k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
+                             double* __restrict__ lam, int* __restrict__ done, double tol, int final_pass)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  if (done[s]) return;
+  double ga = 0, gb = 0, haa = 0, hab = 0, hbb = 0, cnt = 0;
+  for (int64_t c = 0; c < nchunk; ++c) {
+    const double* o = partial + (c * kFitQ) * S + s;
+    ga += o[0]; gb += o[S]; haa += o[2 * S]; hab += o[3 * S]; hbb += o[4 * S]; cnt += o[5 * S];
+  }
+  const double th = ed_pexp(lam[s]);
+  const double p = 1.0 / (1.0 + ed_pexp(-eta[s]));
+  const double q = 1.0 - p;
+  const double a = th * p, b = th * q;
+  double pa, qa, pb, qb, pt, qt;
+  edfit::digamma_trigamma(a, pa, qa);
+  edfit::digamma_trigamma(b, pb, qb);
+  edfit::digamma_trigamma(th, pt, qt);
+  ga -= cnt * (pa - pt);
+  gb -= cnt * (pb - pt);
+  haa -= cnt * (qa - qt);
+  hab += cnt * qt;
+  hbb -= cnt * (qb - qt);
+  const double ae = a * q, be = -b * p;          // d a / d eta, d b / d eta
+  const double g_e = ga * ae + gb * be;
+  const double g_l = ga * a + gb * b;
+  const double h_ee = haa * ae * ae + 2.0 * hab * ae * be + hbb * be * be + (ga * a * q - gb * b * p) * (1.0 - 2.0 * p);
+  const double h_el = haa * ae * a + hab * (ae * b + a * be) + hbb * be * b + ga * ae + gb * be;
+  const double h_ll = haa * a * a + 2.0 * hab * a * b + hbb * b * b + ga * a + gb * b;
+  const double det = h_ee * h_ll - h_el * h_el;
+  double de, dl;
+  if (h_ee < 0.0 && det > 0.0) {
+    de = -(h_ll * g_e - h_el * g_l) / det;
+    dl = -(h_ee * g_l - h_el * g_e) / det;
+  } else {
+    de = g_e / (fabs(h_ee) + 1e-300);
+    dl = g_l / (fabs(h_ll) + fabs(h_el) + 1e-300);
+  }
+  de = fmin(fmax(de, -1.0), 1.0);
+  dl = fmin(fmax(dl, -1.0), 1.0);
+  double ne = eta[s] + de, nl = lam[s] + dl;
+  nl = fmin(fmax(nl, -0.6931471805599453), 18.420680743952367);   // phi in [1e-8, 2/3]
+  ne = fmin(fmax(ne, -20.0), 20.0);
+  eta[s] = ne;
+  lam[s] = nl;
+  if (final_pass && fabs(de) < tol && fabs(dl) < tol) done[s] = 1;
+}
+
+__global__ void k_fit_finish(const double* __restrict__ eta, const double* __restrict__ lam, int64_t S,
+                             double* __restrict__ phi, double* __restrict__ expected)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const double th = ed_pexp(lam[s]);
+  phi[s] = 1.0 / (th + 1.0);                        // phi = 1/(a + b + 1)
+  expected[s] = 1.0 / (1.0 + ed_pexp(-eta[s]));     // fitted(mod) = plogis(eta)
+}
+
 // test hook: element-wise device special functions
 __global__ void k_eval_sf(int which, int64_t n, const double* __restrict__ x, const double* __restrict__ y,
                           double* __restrict__ out)
@@ -387,6 +726,8 @@ __global__ void k_eval_sf(int which, int64_t n, const double* __restrict__ x, co
     case 3: r = __builtin_sqrt(x[i]); break;
     case 4: r = x[i] / y[i]; break;
     case 5: r = ed_psin_0pi(x[i]); break;
+    case 6: { double a, b; edfit::digamma_trigamma(x[i], a, b); r = a; } break;
+    case 7: { double a, b; edfit::digamma_trigamma(x[i], a, b); r = b; } break;
     default: r = ed_pm_nan();
   }
   out[i] = r;
@@ -404,7 +745,10 @@ struct ed_plan {
   double tprob = 0, L = 0;
   std::vector<int32_t> chrom_off;
   int32_t* d_chrom_off = nullptr;
-  double* d_lt = nullptr;  // [(E + C)][9]
+  double* d_lt3 = nullptr;       // [(E + C)][3]  distance-dependent log-transitions per exon gap
+  int64_t* d_tile_off = nullptr;  // [C + 1] back-pointer word offsets per chromosome
+  int64_t n_words = 0;
+  double c0 = 0, c1 = 0;         // log(1 - t), log(t / 2)
 };
 
 struct ed_batch {
@@ -412,6 +756,7 @@ struct ed_batch {
   int64_t S = 0;
   double* d_loglik = nullptr;
   uint8_t* d_path = nullptr;
+  uint64_t* d_bp = nullptr;      // [n_words][S] packed back-pointers
   double* d_consts = nullptr;
   int* d_cflags = nullptr;
   int32_t* d_counts = nullptr;
@@ -419,11 +764,16 @@ struct ed_batch {
   int64_t* d_total = nullptr;
   unsigned long long* d_nerr = nullptr;
   ed_call* d_calls = nullptr;
+  double* d_fit_partial = nullptr;   // [nchunk][6][S]
+  double* d_fit_eta = nullptr;
+  double* d_fit_lam = nullptr;
+  int* d_fit_done = nullptr;
+  int64_t fit_nchunk = 0;
   int64_t calls_cap = 0;
   hipStream_t stream = nullptr;
   bool ran = false;
   bool timing = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_run_times = false, have_fit_time = false;
 };
 
@@ -606,38 +956,63 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
   const double rows[3][3] = {{1. - t, t / 2., t / 2.}, {0.5, 0.5, 0.}, {0.5, 0., 0.5}};
   double T[9];
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T[c * 3 + r] = rows[r][c];
-  std::vector<double> lt((size_t)(n_exons + n_chrom) * 9 + 9);
+  // per gap: the three distance-dependent entries A = lt[0][1] (= lt[0][2]), B = lt[1][1] (= lt[2][2]),
+  // C = lt[1][2] (= lt[2][1]); the symmetric pairs are bitwise equal because rows 1 and 2 of T mirror
+  // each other -- checked below.
+  std::vector<double> lt3((size_t)(n_exons + n_chrom) * 3 + 3);
+  std::vector<int64_t> tile_off((size_t)n_chrom + 1, 0);
+  for (int c = 0; c < n_chrom; ++c) tile_off[c + 1] = tile_off[c] + ((int64_t)(chrom_off[c + 1] - chrom_off[c]) + 7) / 8;
+  p->n_words = tile_off[n_chrom];
+  p->c0 = std::log(T[0]);   // log(1 - t): into normal from normal
+  p->c1 = std::log(T[3]);   // log(t / 2): into a CNV state from normal (T[3] == T[6])
+  bool symmetric = (T[3] == T[6]);
   {
     // one task per chromosome, spread over the host threads
     unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
     std::vector<std::thread> pool;
-    std::vector<int> order(n_chrom);
-    for (int c = 0; c < n_chrom; ++c) order[c] = c;
+    std::vector<char> bad(nt, 0);
     auto work = [&](unsigned tid) {
-      for (int idx = tid; idx < n_chrom; idx += nt) {
-        const int c = order[idx];
+      std::vector<int32_t> pos;
+      std::vector<double> lt9;
+      for (int c = tid; c < n_chrom; c += nt) {
         const int64_t lo = chrom_off[c], hi = chrom_off[c + 1], m = hi - lo;
         if (m <= 0) continue;
-        std::vector<int32_t> pos((size_t)m + 2);
+        pos.resize((size_t)m + 2);
+        lt9.resize((size_t)(m + 1) * 9);
         // as.integer(c(positions[1] - 2*L, positions, end[last] + 2*L))  (R/class_definition.R:368)
         pos[0] = (int32_t)((double)start[lo] - 2 * expected_cnv_length);
         for (int64_t i = 0; i < m; ++i) pos[1 + i] = start[lo + i];
         pos[m + 1] = (int32_t)((double)end[hi - 1] + 2 * expected_cnv_length);
-        fill_log_transitions(T, expected_cnv_length, pos.data(), m + 2, lt.data() + (size_t)(lo + c) * 9);
+        fill_log_transitions(T, expected_cnv_length, pos.data(), m + 2, lt9.data());
+        double* o = lt3.data() + (size_t)(lo + c) * 3;
+        for (int64_t g = 0; g <= m; ++g) {
+          const double* q = lt9.data() + g * 9;
+          o[g * 3 + 0] = q[1]; o[g * 3 + 1] = q[4]; o[g * 3 + 2] = q[5];
+          if (std::memcmp(&q[1], &q[2], 8) || std::memcmp(&q[4], &q[8], 8) || std::memcmp(&q[5], &q[7], 8) ||
+              std::memcmp(&q[0], &p->c0, 8) || std::memcmp(&q[3], &p->c1, 8) || std::memcmp(&q[6], &p->c1, 8))
+            bad[tid] = 1;
+        }
       }
     };
     for (unsigned tid = 1; tid < nt; ++tid) pool.emplace_back(work, tid);
     work(0);
     for (auto& th : pool) th.join();
+    for (char b : bad) if (b) symmetric = false;
   }
-  hipError_t e1 = hipMalloc((void**)&p->d_lt, lt.size() * 8);
+  if (!symmetric) {
+    ed_plan_destroy(p);
+    return ed_fail(ED_ERR_STATE, "ed_plan_create: internal error, log-transition table is not symmetric");
+  }
+  hipError_t e1 = hipMalloc((void**)&p->d_lt3, lt3.size() * 8);
   hipError_t e2 = hipMalloc((void**)&p->d_chrom_off, (size_t)(n_chrom + 1) * 4);
-  if (e1 != hipSuccess || e2 != hipSuccess) {
+  hipError_t e3 = hipMalloc((void**)&p->d_tile_off, (size_t)(n_chrom + 1) * 8);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     ed_plan_destroy(p);
     return ed_fail(ED_ERR_NOMEM, "ed_plan_create: device allocation failed");
   }
-  HIP_TRY(hipMemcpy(p->d_lt, lt.data(), lt.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_lt3, lt3.data(), lt3.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(p->d_chrom_off, chrom_off, (size_t)(n_chrom + 1) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_tile_off, tile_off.data(), (size_t)(n_chrom + 1) * 8, hipMemcpyHostToDevice));
   *plan = p;
   return ED_OK;
 }
@@ -645,7 +1020,8 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
 ED_EXPORT void ed_plan_destroy(ed_plan* p)
 {
   if (!p) return;
-  if (p->d_lt) (void)hipFree(p->d_lt);
+  if (p->d_lt3) (void)hipFree(p->d_lt3);
+  if (p->d_tile_off) (void)hipFree(p->d_tile_off);
   if (p->d_chrom_off) (void)hipFree(p->d_chrom_off);
   delete p;
 }
@@ -669,6 +1045,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes ? bytes : 1) != hipSuccess) ok = false; };
   A((void**)&b->d_loglik, (size_t)E * 3 * S * 8);
   A((void**)&b->d_path, (size_t)E * S);
+  A((void**)&b->d_bp, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 8);
   A((void**)&b->d_consts, (size_t)9 * S * 8);
   A((void**)&b->d_cflags, (size_t)3 * S * 4);
   A((void**)&b->d_counts, (size_t)S * std::max<int64_t>(C, 1) * 4);
@@ -688,7 +1065,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
 ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
-  void* ptrs[] = {b->d_loglik, b->d_path, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_fit_partial, b->d_fit_eta, b->d_fit_lam, b->d_fit_done, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -717,18 +1094,19 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int64_t cells = E * S;
   if (cells > 0)
-    hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((cells + kEmitBlock - 1) / kEmitBlock)), dim3(kEmitBlock), 0, st,
+    hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((cells + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells))), dim3(kEmitBlock), 0, st,
                        d_test, d_ref, b->d_consts, b->d_cflags, E, S, b->d_loglik, b->d_nerr);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
   if (C > 0 && cells > 0)
     hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave), 0, st,
-                       b->d_loglik, p->d_lt, p->d_chrom_off, S, C, b->d_path, b->d_counts);
+                       b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp, b->d_path,
+                       b->d_counts);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, b->d_counts, (C > 0 && cells > 0) ? S * C : 0,
                      b->d_offsets, b->d_total);
   if (C > 0 && cells > 0)
     hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave), 0, st,
-                       b->d_path, p->d_chrom_off, S, C, b->d_offsets, b->d_calls, b->calls_cap);
+                       b->d_path, p->d_chrom_off, S, C, b->d_offsets, b->d_counts, b->d_calls, b->calls_cap);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));
   HIP_TRY(hipGetLastError());
   b->ran = true;
@@ -739,8 +1117,45 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
 ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
                            void* stream_)
 {
-  (void)b; (void)d_test; (void)d_ref; (void)d_phi; (void)d_expected; (void)stream_;
-  return ed_fail(ED_ERR_STATE, "ed_batch_fit: dispersion-fit kernel not built yet");
+  if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_fit: NULL argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const int64_t E = b->plan->E, S = b->S;
+  if (E <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_fit: no exons");
+  const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
+  if (!b->d_fit_partial) {
+    b->fit_nchunk = nblk * kFitSub;
+    HIP_TRY(hipMalloc((void**)&b->d_fit_partial, (size_t)b->fit_nchunk * kFitQ * S * 8));
+    HIP_TRY(hipMalloc((void**)&b->d_fit_eta, (size_t)S * 8));
+    HIP_TRY(hipMalloc((void**)&b->d_fit_lam, (size_t)S * 8));
+    HIP_TRY(hipMalloc((void**)&b->d_fit_done, (size_t)S * 4));
+  }
+  b->stream = st;
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
+  const dim3 grid((unsigned)((S + kWave - 1) / kWave), (unsigned)nblk), block(kWave, kFitSub);
+  const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
+  // chunks that the strided passes do not touch must not contribute: every pass rewrites all partials
+  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, d_ref, E, S, 4, b->d_fit_partial);
+  hipLaunchKernelGGL(k_fit_start, g1, b1, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
+                     b->d_fit_done);
+  // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
+  const int coarse = (E >= 64 * 16) ? 4 : 0;
+  for (int it = 0; it < coarse; ++it) {
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, d_ref, E, S, 16, b->d_fit_eta, b->d_fit_lam,
+                       b->d_fit_done, b->d_fit_partial);
+    hipLaunchKernelGGL(k_fit_update, g1, b1, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
+                       b->d_fit_done, 1e-10, 0);
+  }
+  for (int it = 0; it < 8; ++it) {
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, d_ref, E, S, 1, b->d_fit_eta, b->d_fit_lam,
+                       b->d_fit_done, b->d_fit_partial);
+    hipLaunchKernelGGL(k_fit_update, g1, b1, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
+                       b->d_fit_done, 1e-10, 1);
+  }
+  hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, b->d_fit_eta, b->d_fit_lam, S, d_phi, d_expected);
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[6], st));
+  HIP_TRY(hipGetLastError());
+  b->have_fit_time = b->timing;
+  return ED_OK;
 }
 
 ED_EXPORT const double* ed_batch_loglik(const ed_batch* b) { return b ? b->d_loglik : nullptr; }
@@ -810,6 +1225,10 @@ ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
   if (b->have_run_times) {
     HIP_TRY(hipEventSynchronize(b->ev[4]));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+  }
+  if (b->have_fit_time) {
+    HIP_TRY(hipEventSynchronize(b->ev[6]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], b->ev[5], b->ev[6]));
   }
   return ED_OK;
 }

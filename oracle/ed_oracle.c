@@ -274,6 +274,8 @@ EDO_API long edo_callcnvs(const double *likelihood, long n, const int *chrom_off
   return ncalls;
 }
 
+#include "edo_fit.inc"
+
 /* =====================================================================================
  * Loader for oracle/_ref/libgslsf_ref.so -- the reference's own special-function sources compiled
  * as they lie (oracle/Makefile).  That library has exactly one unresolved symbol, gsl_error, whose

@@ -54,6 +54,12 @@ def lib():
         L.edo_ref_call2.argtypes = [C.c_char_p, C.c_long, _dp, _dp, _dp]
         L.edo_ref_call2.restype = C.c_int
         L.edo_now.restype = C.c_double
+        L.edo_psi_v.argtypes = [C.c_long, _dp, _dp, _dp]
+        L.edo_psi_v.restype = None
+        L.edo_fit_mle.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.edo_fit_mle.restype = C.c_int
+        L.edo_fit_nm.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.edo_fit_nm.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -138,6 +144,29 @@ def callcnvs(likelihood, chrom_off, start, end, transition_probability=1e-4, exp
     nc = lib().edo_callcnvs(llc, n, chrom_off, chrom_off.size - 1, _i32(start), _i32(end),
                             float(transition_probability), float(expected_cnv_length), path, calls, cap)
     return path, calls[:nc].copy()
+
+
+def psi(x):
+    """(digamma, trigamma) of the checker (long double inside)."""
+    x = _f64(x); a = np.empty_like(x); b = np.empty_like(x)
+    lib().edo_psi_v(x.size, x, a, b)
+    return a, b
+
+
+def fit_mle(test, ref):
+    """High-precision MLE of (phi, p) for  cbind(test, reference) ~ 1  (parity unpinned: see edo_fit.inc)."""
+    test = _i32(test); ref = _i32(ref)
+    phi, p, ll = C.c_double(), C.c_double(), C.c_double()
+    it = lib().edo_fit_mle(test, ref, test.size, C.byref(phi), C.byref(p), C.byref(ll))
+    return phi.value, p.value, ll.value, it
+
+
+def fit_nm(test, ref):
+    """Nelder-Mead stand-in for aod::betabin (timing baseline only)."""
+    test = _i32(test); ref = _i32(ref)
+    phi, p, ne = C.c_double(), C.c_double(), C.c_int()
+    lib().edo_fit_nm(test, ref, test.size, C.byref(phi), C.byref(p), C.byref(ne))
+    return phi.value, p.value, ne.value
 
 
 # ---- the reference's own special functions, compiled as they lie (container only) ----

@@ -1,0 +1,84 @@
+"""Dispersion fit (kernel group K5) against the checker's high-precision MLE.
+
+Parity status: UNPINNED against the reference -- phi/expected come from aod::betabin there
+(R/class_definition.R:118), a third-party package outside the reference tree.  What is tested is that
+the device reaches the maximum of the documented likelihood: (phi, p) within FIT_REL_TOL of the
+checker's long-double Newton solution, and within Nelder-Mead's own tolerance of the aod stand-in.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import eval_sf
+
+pytestmark = pytest.mark.gpu
+
+FIT_REL_TOL = 1e-8
+
+
+def test_device_digamma_trigamma(edlib, oracle):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-2), np.log(1e7), 200_000)), [0.5, 1.0, 9.999, 10.0, 10.001]])
+    psi, psi1 = oracle.psi(x)
+    got0 = eval_sf(edlib, 6, x)
+    got1 = eval_sf(edlib, 7, x)
+    # psi crosses zero at x0 = 1.4616...: absolute bound there, relative elsewhere
+    assert np.max(np.abs(got0 - psi) / np.maximum(np.abs(psi), 1.0)) < 5e-15
+    assert np.max(np.abs(got1 - psi1) / np.abs(psi1)) < 5e-15
+
+
+def _fit_case(edlib, oracle, E, S, seed, **kw):
+    from exomedepth_amd import synth
+    chrom_off, start, end = synth.exon_design(E, 4, seed)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=5, **kw)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dphi = edlib.DeviceArray(np.zeros(S))
+    dexp = edlib.DeviceArray(np.zeros(S))
+    batch.fit(test, ref, dphi, dexp)
+    from exomedepth_amd._lib import check, lib
+    check(lib().ed_synchronize(None))
+    gphi, gexp = dphi.to_host(), dexp.to_host()
+    batch.close(); plan.close()
+    for s in range(S):
+        ophi, op, _, _ = oracle.fit_mle(test[:, s], ref[:, s])
+        assert abs(gphi[s] - ophi) / ophi < FIT_REL_TOL, (s, gphi[s], ophi)
+        assert abs(gexp[s] - op) / op < FIT_REL_TOL, (s, gexp[s], op)
+    return test, ref, gphi, gexp
+
+
+def test_fit_matches_high_precision_mle(edlib, oracle):
+    _fit_case(edlib, oracle, E=6000, S=70, seed=41)
+
+
+def test_fit_short_and_low_depth(edlib, oracle):
+    _fit_case(edlib, oracle, E=300, S=5, seed=42)                      # fewer exons than one coarse stride pass
+    _fit_case(edlib, oracle, E=4000, S=9, seed=43, mean_depth=8.0)     # low depth: small shape arguments
+
+
+def test_fit_vs_neldermead_standin(edlib, oracle):
+    test, ref, gphi, gexp = _fit_case(edlib, oracle, E=5000, S=3, seed=44)
+    for s in range(3):
+        nphi, npp, _ = oracle.fit_nm(test[:, s], ref[:, s])
+        assert abs(gphi[s] - nphi) / nphi < 2e-2    # optim()'s reltol 1.5e-8 on the objective ~ 1e-3..1e-2 on phi
+        assert abs(gexp[s] - npp) / npp < 2e-3
+
+
+def test_fit_then_run_end_to_end(edlib, oracle):
+    """fit -> emissions -> Viterbi on the device; the checker, fed the device's (phi, p), must agree bit for bit."""
+    from exomedepth_amd import synth
+    E, S = 3000, 6
+    chrom_off, start, end = synth.exon_design(E, 3, 51)
+    test, ref, _, _, _ = synth.counts_numpy(chrom_off, S, 51, n_segments=3, mean_depth=70.0)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dphi = edlib.DeviceArray(np.zeros(S)); dexp = edlib.DeviceArray(np.zeros(S))
+    batch.fit(test, ref, dphi, dexp)
+    batch.run(test, ref, dphi, dexp)
+    ll, path = batch.loglik(), batch.path()
+    gphi, gexp = dphi.to_host(), dexp.to_host()
+    batch.close(); plan.close()
+    for s in range(S):
+        ell, _ = oracle.get_loglike_matrix(gphi[s], gexp[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.PORTABLE)
+        assert np.array_equal(ll[:, :, s].view(np.int64), np.ascontiguousarray(ell).view(np.int64))
+        ep, _ = oracle.callcnvs(ell, chrom_off, start, end)
+        assert np.array_equal(path[:, s].astype(np.int8), ep)
