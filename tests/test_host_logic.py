@@ -1,0 +1,56 @@
+"""Host-side logic of the interface mirror (no GPU): exon ordering of CallCNVs, R-style coercions,
+synthetic generators, sample sharding."""
+import numpy as np
+
+import exomedepth_amd as ed
+from exomedepth_amd import api, dist, synth
+
+
+def test_chromosome_order_follows_callcnvs():
+    """reference R/class_definition.R:323-336: levels = '1'..'22' (those present) then the other names in
+    first-seen order; exons ordered by (level, midpoint), ties in input order."""
+    chrom = ["X", "2", "10", "2", "chrM", "1", "X", "10", "2"]
+    start = [50, 300, 10, 100, 5, 70, 10, 10, 100]
+    end = [60, 400, 20, 200, 9, 90, 20, 20, 200]
+    order, levels, codes, off = ed.chromosome_order(chrom, start, end)
+    assert levels == ["1", "2", "10", "X", "chrM"]
+    assert [chrom[i] for i in order] == ["1", "2", "2", "2", "10", "10", "X", "X", "chrM"]
+    assert order.tolist() == [5, 3, 8, 1, 2, 7, 6, 0, 4]      # the two identical chr2 exons keep input order
+    assert off.tolist() == [0, 1, 4, 6, 8, 9]
+
+
+def test_r_style_coercions():
+    assert api._as_r_integer(np.array([1.9, -1.9, 3.0])).tolist() == [1, -1, 3]     # as.integer truncates
+    assert api._signif(123456.0, 3) == 123000.0 and api._signif(0.0123456, 3) == 0.0123
+    assert api._signif(-2.3456, 3) == -2.35 and api._signif(0.0, 3) == 0.0
+
+
+def test_synthetic_design_and_counts_are_deterministic_and_sane():
+    off, start, end = synth.exon_design(5000, 24, seed=3)
+    off2, start2, end2 = synth.exon_design(5000, 24, seed=3)
+    assert np.array_equal(start, start2) and off[-1] == 5000 and len(off) == 25
+    for c in range(24):
+        s = start[off[c]:off[c + 1]]
+        assert np.all(np.diff(s) > 0)
+    assert np.all(end > start) and start.dtype == np.int32
+    test, ref, p, phi, state = synth.counts_numpy(off, 8, seed=4, n_segments=4)
+    assert test.shape == (5000, 8) and test.dtype == np.int32 and np.all(test >= 0) and np.all(ref >= 0)
+    frac = test.sum(axis=0) / (test.sum(axis=0) + ref.sum(axis=0))
+    assert np.all(np.abs(frac - p) < 0.01)
+    assert 0 < (state != 0).mean() < 0.05
+
+
+def test_shard_bounds_partition_the_sample_axis():
+    for S, W in ((8192, 8), (10, 3), (5, 8), (1024, 1)):
+        b = [dist.shard_bounds(S, r, W) for r in range(W)]
+        assert b[0][0] == 0 and b[-1][1] == S
+        assert all(b[i][1] == b[i + 1][0] for i in range(W - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_exomedepth_low_coverage_guard():
+    """reference R/class_definition.R:94-97: fewer than 5 bins with more than 5 reads -> empty object."""
+    x = ed.ExomeDepth(np.array([0, 1, 2, 9, 9, 9, 9]), np.array([5, 5, 5, 50, 50, 50, 50]))
+    assert x.phi.size == 0 and x.likelihood.shape == (0, 3)
+    assert x.CallCNVs(["1"] * 7, range(7), range(1, 8), list("abcdefg")).CNV_calls == []

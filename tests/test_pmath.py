@@ -1,0 +1,42 @@
+"""Accuracy of the portable log/exp/sin definitions (exomedepth_amd/csrc/ed_pmath.h) that both the
+device code and the checker's portable flavour evaluate."""
+import mpmath as mp
+import numpy as np
+
+mp.mp.dps = 40
+
+
+def _max_ulp(f, x, got):
+    worst = 0.0
+    for xi, gi in zip(x, got):
+        t = f(mp.mpf(float(xi)))
+        if t == 0:
+            continue
+        ulp = mp.mpf(2) ** (mp.floor(mp.log(abs(t), 2)) - 52)
+        worst = max(worst, float(abs(mp.mpf(float(gi)) - t) / ulp))
+    return worst
+
+
+def test_plog(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 1500)), rng.uniform(0.5, 2, 1500), 1 + rng.uniform(-1e-3, 1e-3, 800),
+                        [5e-324, 2.2250738585072014e-308, 1.7976931348623157e308]])
+    assert _max_ulp(mp.log, x, oracle.plog(x)) < 0.8
+    sp = oracle.plog(np.array([0.0, -1.0, np.inf, np.nan, 1.0]))
+    assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and np.isnan(sp[3]) and sp[4] == 0.0
+    big = np.exp(rng.uniform(-5, 12, 200000))
+    assert np.max(np.abs(oracle.plog(big) - np.log(big)) / np.abs(np.log(big) + 1e-300) * (np.abs(np.log(big)) > 1e-3)) < 3e-16
+
+
+def test_pexp(oracle):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-700, 700, 2000), rng.uniform(-1, 1, 1500), rng.uniform(0, 0.01, 800)])
+    assert _max_ulp(mp.exp, x, oracle.pexp(x)) < 0.9
+    sp = oracle.pexp(np.array([-746.0, 710.0, np.nan, 0.0, -745.0]))
+    assert sp[0] == 0.0 and sp[1] == np.inf and np.isnan(sp[2]) and sp[3] == 1.0 and sp[4] == 5e-324
+
+
+def test_psin(oracle):
+    x = np.random.default_rng(2).uniform(0, np.pi, 3000)
+    assert _max_ulp(mp.sin, x, oracle.psin(x)) < 1.7
+    assert np.isnan(oracle.psin(np.array([-0.1, 3.2]))).all()
