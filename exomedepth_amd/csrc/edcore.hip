@@ -304,137 +304,224 @@ __device__ __forceinline__ int summarise_chain(int64_t last, TB tb, EMIT emit)
 }
 
 // ---- batched chains -------------------------------------------------------------------------
-// Block = one wave; lane = sample; blockIdx.y = chromosome.  A chain is strictly sequential (the
-// max-plus recurrence is evaluated in the reference's association order, so no scan), which makes the
-// kernel latency-bound: what matters is how many loads each wave keeps in flight.
-//   loglik [E][3][S]  S4 column order (deletion, normal, duplication): HMM state j reads column {1,0,2}[j].
-//                     Emissions are fetched a whole tile of kVitTile steps ahead (register double buffer).
-//   lt3    [(E+C)][3] the three distance-dependent log-transitions of CallCNVs' matrix per exon gap
-//                     (A = into normal from a CNV state, B = staying in a CNV state, C = switching CNV
-//                     state); the two constants c0 = log(1-t), c1 = log(t/2) are kernel arguments.
-//                     gap index of padded step i of chromosome c: lo + c + (i-1).  Wave-uniform -> scalar loads.
-//   bp64   [tiles][S] back-pointers, 8 steps x 6 bits per word, one coalesced 8-byte store per 8 steps
-//   path   [E][S]     Viterbi state per exon, written by the trace-back
-// The two dummy observations of CallCNVs (R/class_definition.R:364) are implicit: the chain starts
-// from (0,-inf,-inf) (src/hmm.cpp:48-52; the first dummy row is never read) and ends with one extra
-// step whose emissions are (-100, 0, -100).
-constexpr int kVitTile = 16;  // emission prefetch tile (steps); a multiple of 8
+// A chain (one sample x one chromosome) is strictly sequential: the max-plus recurrence is evaluated in
+// the reference's association order, so there is no scan over exons.  The parallelism inside a chain
+// is the 3 target states: a chain is run by a QUAD of lanes (lane j of the quad owns HMM state j; the
+// 4th lane shadows state 0), 16 chains per wave.  Per step a lane needs the three previous scores --
+// two DPP quad-broadcasts away -- its own emission and its own row of log-transitions:
+//       cand_k = (e_j + v_k) + lt[j][k],  k = 0,1,2   (src/hmm.cpp:79; first strict maximum wins, :81-84)
+// This cuts the per-step instruction count ~2.5x against one-lane-per-chain and quadruples the waves
+// that hide each other's latency; the chain of the longest chromosome is the critical path.
+//   loglik [E][3][S]   S4 column order (deletion, normal, duplication): state j reads column {1,0,2}[j];
+//                      fetched kVitTile steps ahead (register double buffer)
+//   lt4    [(E+C)][4][2]  per exon gap and per quad lane the pair (lt[j][1], lt[j][2]) of CallCNVs' matrix:
+//                      lane 0/3: (A, A), lane 1: (B, C), lane 2: (C, B);  lt[j][0] is a per-lane constant
+//                      (c0 = log(1-t) for state 0, c1 = log(t/2) otherwise).  gap of padded step i of
+//                      chromosome c: lo + c + (i-1).  All quads of a wave read the same 64 bytes.
+//   bpq    [words][S][4]  back-pointers: each lane keeps the 2-bit pointers of ITS state, 16 steps per
+//                      32-bit word, one coalesced 4-byte store per lane per 16 steps
+//   ppath  [words][S]  Viterbi states written by the trace-back, 16 exons x 2 bits per word (one store per
+//                      16 steps keeps the trace-back's loads from queueing behind byte stores);
+//                      k_path_expand turns it into the byte-per-exon path [E][S] of the interface
+// The two dummy observations of CallCNVs (R/class_definition.R:364) are implicit: the chain starts from
+// (0,-inf,-inf) (src/hmm.cpp:48-52; the first dummy row is never read) and ends with one extra step
+// whose emissions are (-100, 0, -100).
+constexpr int kVitTile = 16;      // steps per back-pointer / packed-state word
+constexpr int kFwdTile = 16;      // forward prefetch tile (steps); a multiple of kVitTile
+constexpr int kVitChains = 16;    // chains per wave
 
-// One forward step for CallCNVs' transition matrix (src/hmm.cpp:68-88 with R/class_definition.R:343-347):
-// lt[j][k]: j=0: (c0, A, A); j=1: (c1, B, C); j=2: (c1, C, B).  Candidate order k=0,1,2 and the strict
-// '>' reproduce the reference's tie-breaking; a state no candidate improves on points to 0.
-__device__ __forceinline__ unsigned vit_step3(double& v0, double& v1, double& v2, double e0, double e1, double e2,
-                                              double c0, double c1, double A, double B, double C)
+template <int K>
+__device__ __forceinline__ double quad_bcast(double x)
 {
-  const double NI = -HUGE_VAL;
-  double b0 = NI, b1 = NI, b2 = NI;
-  unsigned f0 = 0, f1 = 0, f2 = 0;
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), K * 0x55, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), K * 0x55, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast_i(int x)
+{
+  return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, true);
+}
+
+// one forward step of the lane's state; returns the 2-bit back-pointer
+__device__ __forceinline__ unsigned vit_step_q(double& v, double e, double t0, double t1, double t2)
+{
+  const double v0 = quad_bcast<0>(v), v1 = quad_bcast<1>(v), v2 = quad_bcast<2>(v);
+  double best = -HUGE_VAL;
+  unsigned fw = 0;
   double cand;
-  cand = (e0 + v0) + c0; if (cand > b0) { b0 = cand; f0 = 0; }
-  cand = (e0 + v1) + A;  if (cand > b0) { b0 = cand; f0 = 1; }
-  cand = (e0 + v2) + A;  if (cand > b0) { b0 = cand; f0 = 2; }
-  cand = (e1 + v0) + c1; if (cand > b1) { b1 = cand; f1 = 0; }
-  cand = (e1 + v1) + B;  if (cand > b1) { b1 = cand; f1 = 1; }
-  cand = (e1 + v2) + C;  if (cand > b1) { b1 = cand; f1 = 2; }
-  cand = (e2 + v0) + c1; if (cand > b2) { b2 = cand; f2 = 0; }
-  cand = (e2 + v1) + C;  if (cand > b2) { b2 = cand; f2 = 1; }
-  cand = (e2 + v2) + B;  if (cand > b2) { b2 = cand; f2 = 2; }
-  if (e0 == NI) f0 = 0;
-  if (e1 == NI) f1 = 0;
-  if (e2 == NI) f2 = 0;
-  v0 = b0; v1 = b1; v2 = b2;
-  return f0 | (f1 << 2) | (f2 << 4);
+  cand = (e + v0) + t0; if (cand > best) { best = cand; fw = 0; }
+  cand = (e + v1) + t1; if (cand > best) { best = cand; fw = 1; }
+  cand = (e + v2) + t2; if (cand > best) { best = cand; fw = 2; }
+  if (e == -HUGE_VAL) fw = 0;   // src/hmm.cpp:87
+  v = best;
+  return fw;
 }
 
 __global__ void __launch_bounds__(kWave)
-k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt3, double c0, double c1,
-          const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ tile_off, int64_t S, int32_t C,
-          uint64_t* __restrict__ bp64, uint8_t* __restrict__ path, int32_t* __restrict__ counts)
+k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, double c0, double c1,
+          const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off, int64_t S, int32_t C,
+          uint32_t* __restrict__ bpq, uint32_t* __restrict__ ppath, int32_t* __restrict__ counts,
+          const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom)
 {
-  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  const int c = blockIdx.y;
-  if (s >= S) return;
+  const int lane = threadIdx.x;
+  const int j = lane & 3;
+  const int64_t s_raw = (int64_t)blockIdx.x * kVitChains + (lane >> 2);
+  const bool live = s_raw < S;
+  const int64_t s = live ? s_raw : S - 1;   // idle quads shadow the last sample (loads stay in bounds, no stores)
+  __shared__ double2 lds_lt[2][kFwdTile][4];
+  // A workgroup runs a JOB: one or more whole chromosomes, one after the other.  The host packs the
+  // chromosomes into jobs of about the longest chromosome's length so that, when the batch has fewer
+  // waves than the chip has SIMDs, every wave has a SIMD to itself and the makespan is one long chain.
+  for (int jc = job_off[blockIdx.y]; jc < job_off[blockIdx.y + 1]; ++jc) {
+  const int c = job_chrom[jc];
   const int64_t lo = chrom_off[c], hi = chrom_off[c + 1];
   const int64_t m = hi - lo;
   if (m <= 0) {
-    counts[s * C + c] = 0;
-    return;
+    if (live && j == 0) counts[s * C + c] = 0;
+    continue;
   }
-  const double* __restrict__ em = loglik + (lo * 3) * S + s;   // step i, column col: em[(i*3+col)*S]
-  const double* __restrict__ l3 = lt3 + (lo + c) * 3;
-  uint64_t* __restrict__ bpc = bp64 + tile_off[c] * S + s;      // word w of this chain: bpc[w*S]
-  uint8_t* __restrict__ pth = path + lo * S + s;                // exon i of this chain: pth[i*S]
-  double v0 = 0., v1 = -HUGE_VAL, v2 = -HUGE_VAL;
+  __syncthreads();   // the previous chromosome's readers are done with lds_lt
+  const int col = (j == 1) ? 0 : ((j == 2) ? 2 : 1);
+  const int64_t estride = 3 * S;                                  // doubles between consecutive exons
+  const double* __restrict__ em = loglik + (lo * 3 + col) * S + s; // step i: em[i * estride]
+  const double2* __restrict__ ltp = reinterpret_cast<const double2*>(lt4) + (lo + c) * 4 + j;  // step i: ltp[i * 4]
+  uint32_t* __restrict__ bpc = bpq + (word_off[c] * S + s) * 4 + j;                            // word w: bpc[w * S * 4]
+  const int64_t wstride = S * 4;
+  uint32_t* __restrict__ ppc = ppath + word_off[c] * S + s;   // packed states of word w: ppc[w * S]
+  const double t0 = (j == 0 || j == 3) ? c0 : c1;
+  double v = (j == 0 || j == 3) ? 0.0 : -HUGE_VAL;
 
   // ---- forward pass ----
-  double cur[kVitTile][3], nxt[kVitTile][3];
-  auto load_tile = [&](double (&t)[kVitTile][3], int64_t base) {
+  // Tiles of kFwdTile steps.  Emissions of tile t+1 are in flight (registers) while tile t is computed;
+  // the log-transitions of tile t+1 are fetched by the wave as one 16-byte load per lane per 16 steps,
+  // parked in LDS, and read back per step (every quad reads the same 64 bytes, its lane its own 16).
+  // Full tiles run without per-step guards (the table carries padding, so its prefetch may run past the
+  // chromosome's last gap); the remaining < kFwdTile steps take a plain loop.
+  const int64_t nfull = m / kFwdTile;
+  double ecur[kFwdTile], enxt[kFwdTile];
+  double2 stage[kFwdTile / 16];
+  const double2* __restrict__ ltw = reinterpret_cast<const double2*>(lt4) + (lo + c) * 4;   // wave-level view
+  if (nfull > 0) {
 #pragma unroll
-    for (int k = 0; k < kVitTile; ++k) {
-      const int64_t i = base + k;
-      if (i < m) {
-        const double* q = em + (i * 3) * S;
-        t[k][0] = q[S]; t[k][1] = q[0]; t[k][2] = q[2 * S];
-      } else {
-        t[k][0] = 0.; t[k][1] = 0.; t[k][2] = 0.;
-      }
-    }
-  };
-  load_tile(cur, 0);
-  for (int64_t base = 0; base < m; base += kVitTile) {
-    if (base + kVitTile < m) load_tile(nxt, base + kVitTile);
+    for (int r = 0; r < kFwdTile / 16; ++r) stage[r] = ltw[r * 64 + lane];
 #pragma unroll
-    for (int h = 0; h < kVitTile / 8; ++h) {
-      uint64_t w = 0;
+    for (int k = 0; k < kFwdTile; ++k) ecur[k] = em[k * estride];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int64_t i = base + h * 8 + k;
-        if (i < m) {
-          const unsigned bp = vit_step3(v0, v1, v2, cur[h * 8 + k][0], cur[h * 8 + k][1], cur[h * 8 + k][2], c0, c1,
-                                        l3[i * 3 + 0], l3[i * 3 + 1], l3[i * 3 + 2]);
-          w |= (uint64_t)bp << (6 * k);
-        }
-      }
-      if (base + h * 8 < m) bpc[((base >> 3) + h) * S] = w;
-    }
-#pragma unroll
-    for (int k = 0; k < kVitTile; ++k) { cur[k][0] = nxt[k][0]; cur[k][1] = nxt[k][1]; cur[k][2] = nxt[k][2]; }
+    for (int r = 0; r < kFwdTile / 16; ++r) (&lds_lt[0][0][0])[r * 64 + lane] = stage[r];
+    __syncthreads();
   }
-  // dummy last observation: only the back-pointer of state 0 is ever used (src/hmm.cpp:96)
+  for (int64_t t = 0; t < nfull; ++t) {
+    const int64_t base = t * kFwdTile;
+    const int buf = (int)(t & 1);
+    const bool more = t + 1 < nfull;
+    if (more) {
+      const double2* __restrict__ lq = ltw + (base + kFwdTile) * 4;
+#pragma unroll
+      for (int r = 0; r < kFwdTile / 16; ++r) stage[r] = lq[r * 64 + lane];
+      const double* __restrict__ q = em + (base + kFwdTile) * estride;
+#pragma unroll
+      for (int k = 0; k < kFwdTile; ++k) enxt[k] = q[k * estride];
+    }
+#pragma unroll
+    for (int h = 0; h < kFwdTile / kVitTile; ++h) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int k = 0; k < kVitTile; ++k) {
+        const double2 l = lds_lt[buf][h * kVitTile + k][j];
+        const unsigned fw = vit_step_q(v, ecur[h * kVitTile + k], t0, l.x, l.y);
+        w |= fw << (2 * k);
+      }
+      if (live) bpc[(t * (kFwdTile / kVitTile) + h) * wstride] = w;
+    }
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < kFwdTile / 16; ++r) (&lds_lt[buf ^ 1][0][0])[r * 64 + lane] = stage[r];
+#pragma unroll
+      for (int k = 0; k < kFwdTile; ++k) ecur[k] = enxt[k];
+    }
+    __syncthreads();
+  }
+  {
+    // the remaining steps (fewer than kFwdTile), one back-pointer word per 16
+    uint32_t w = 0;
+    for (int64_t i = nfull * kFwdTile; i < m; ++i) {
+      const double2 l = ltp[i * 4];
+      const unsigned fw = vit_step_q(v, em[i * estride], t0, l.x, l.y);
+      w |= fw << (2 * (int)(i & (kVitTile - 1)));
+      if ((i & (kVitTile - 1)) == kVitTile - 1 || i == m - 1) {
+        if (live) bpc[(i / kVitTile) * wstride] = w;
+        w = 0;
+      }
+    }
+  }
+  // dummy last observation (R/class_definition.R:364): only state 0's back-pointer is ever used
   int st;
   {
-    const unsigned bp = vit_step3(v0, v1, v2, -100., 0., -100., c0, c1, l3[m * 3 + 0], l3[m * 3 + 1], l3[m * 3 + 2]);
-    st = bp & 3;
+    const double2 l = ltp[m * 4];
+    const double e = (j == 1) ? 0.0 : -100.0;
+    const unsigned fw = vit_step_q(v, e, t0, l.x, l.y);
+    st = quad_bcast_i<0>((int)fw);
   }
   // ---- trace back (src/hmm.cpp:95-100) + call count ----
-  // A call is pushed by the reference's summary loop (src/hmm.cpp:109-121) exactly where a run of a
-  // non-zero state ends, so the count is the number of positions q with tb[q] != tb[q+1], tb[q] != 0.
-  const int64_t nw = (m + 7) >> 3;
-  int count = 0, after = 0;   // after = state of the observation following the current one
+  // All four lanes of the quad walk the same path; each holds the back-pointers of its own state, so the
+  // pointer to follow is a quad broadcast selected by the current state.  A call is pushed by the
+  // reference's summary loop (src/hmm.cpp:109-121) exactly where a run of a non-zero state ends, so the
+  // count is the number of positions q with tb[q] != tb[q+1], tb[q] != 0.
+  int count = 0, after = 0;
+  uint32_t pw = 0;   // Viterbi states of the current 16-exon word, 2 bits each
+  auto back = [&](uint32_t ww, int k) {
+    pw |= (uint32_t)st << (2 * k);
+    count += (st != after && st != 0) ? 1 : 0;
+    after = st;
+    const int f = (int)((ww >> (2 * k)) & 3);
+    const int f0 = quad_bcast_i<0>(f), f1 = quad_bcast_i<1>(f), f2 = quad_bcast_i<2>(f);
+    st = (st == 0) ? f0 : ((st == 1) ? f1 : f2);
+  };
+  const int64_t nwfull = m / kVitTile;   // full 16-step words
+  if (m > nwfull * kVitTile) {
+    const uint32_t ww = (uint32_t)bpc[nwfull * wstride];
+    for (int64_t i = m - 1; i >= nwfull * kVitTile; --i) back(ww, (int)(i & (kVitTile - 1)));
+    if (live && j == 0) ppc[nwfull * S] = pw;
+    pw = 0;
+  }
   constexpr int kDepth = 4;   // back-pointer words kept in flight
-  uint64_t ring[kDepth];
+  uint32_t ring[kDepth];
 #pragma unroll
-  for (int d = 0; d < kDepth; ++d) ring[d] = (nw - 1 - d >= 0) ? bpc[(nw - 1 - d) * S] : 0;
-  for (int64_t wb = nw - 1; wb >= 0; wb -= kDepth) {
+  for (int d = 0; d < kDepth; ++d) ring[d] = (nwfull - 1 - d >= 0) ? (uint32_t)bpc[(nwfull - 1 - d) * wstride] : 0u;
+  for (int64_t wb = nwfull - 1; wb >= 0; wb -= kDepth) {
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
       const int64_t wi = wb - d;
       if (wi < 0) break;
-      const uint64_t w = ring[d];
-      if (wi - kDepth >= 0) ring[d] = bpc[(wi - kDepth) * S];
+      const uint32_t ww = ring[d];
+      if (wi - kDepth >= 0) ring[d] = (uint32_t)bpc[(wi - kDepth) * wstride];
 #pragma unroll
-      for (int k = 7; k >= 0; --k) {
-        const int64_t i = wi * 8 + k;
-        if (i < m) {
-          pth[i * S] = (uint8_t)st;
-          count += (st != after && st != 0) ? 1 : 0;
-          after = st;
-          st = (int)((w >> (6 * k + 2 * st)) & 3);
-        }
-      }
+      for (int k = kVitTile - 1; k >= 0; --k) back(ww, k);
+      if (live && j == 0) ppc[wi * S] = pw;
+      pw = 0;
     }
   }
-  counts[s * C + c] = count;
+  if (live && j == 0) counts[s * C + c] = count;
+  }   // chromosomes of the job
+}
+
+// packed states [words][S] -> path [E][S] (one byte per exon).  thread = (sample, word)
+__global__ void __launch_bounds__(256)
+k_path_expand(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chrom_off,
+              const int64_t* __restrict__ word_off, int64_t S, uint8_t* __restrict__ path)
+{
+  const int64_t s = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int c = blockIdx.z;
+  const int64_t lo = chrom_off[c], m = chrom_off[c + 1] - lo;
+  const int64_t w = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (s >= S || w * kVitTile >= m) return;
+  const uint32_t pw = ppath[(word_off[c] + w) * S + s];
+  uint8_t* __restrict__ o = path + (lo + w * kVitTile) * S + s;
+  const int64_t left = m - w * kVitTile;
+#pragma unroll
+  for (int k = 0; k < kVitTile; ++k)
+    if (k < left) o[k * S] = (uint8_t)((pw >> (2 * k)) & 3);
 }
 
 // exclusive scan of n int32 counts by one workgroup; total written to *total
@@ -745,9 +832,10 @@ struct ed_plan {
   double tprob = 0, L = 0;
   std::vector<int32_t> chrom_off;
   int32_t* d_chrom_off = nullptr;
-  double* d_lt3 = nullptr;       // [(E + C)][3]  distance-dependent log-transitions per exon gap
-  int64_t* d_tile_off = nullptr;  // [C + 1] back-pointer word offsets per chromosome
+  double* d_lt3 = nullptr;       // [(E + C)][4][2]  per exon gap and quad lane: (lt[j][1], lt[j][2])
+  int64_t* d_tile_off = nullptr;  // [C + 1] back-pointer word offsets (16 steps per word) per chromosome
   int64_t n_words = 0;
+  int64_t max_words = 0;
   double c0 = 0, c1 = 0;         // log(1 - t), log(t / 2)
 };
 
@@ -756,7 +844,11 @@ struct ed_batch {
   int64_t S = 0;
   double* d_loglik = nullptr;
   uint8_t* d_path = nullptr;
-  uint64_t* d_bp = nullptr;      // [n_words][S] packed back-pointers
+  uint32_t* d_bp = nullptr;      // [n_words][S][4] packed back-pointers (16 steps x 2 bits per quad lane)
+  uint32_t* d_ppath = nullptr;   // [n_words][S] packed Viterbi states (16 exons x 2 bits)
+  int32_t* d_job_off = nullptr;  // [n_jobs + 1]
+  int32_t* d_job_chrom = nullptr;  // chromosomes in job order
+  int32_t n_jobs = 0;
   double* d_consts = nullptr;
   int* d_cflags = nullptr;
   int32_t* d_counts = nullptr;
@@ -959,10 +1051,11 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
   // per gap: the three distance-dependent entries A = lt[0][1] (= lt[0][2]), B = lt[1][1] (= lt[2][2]),
   // C = lt[1][2] (= lt[2][1]); the symmetric pairs are bitwise equal because rows 1 and 2 of T mirror
   // each other -- checked below.
-  std::vector<double> lt3((size_t)(n_exons + n_chrom) * 3 + 3);
+  std::vector<double> lt3((size_t)(n_exons + n_chrom + 128) * 8, 0.0);   // +128 gaps: the kernel's prefetch may over-read
   std::vector<int64_t> tile_off((size_t)n_chrom + 1, 0);
-  for (int c = 0; c < n_chrom; ++c) tile_off[c + 1] = tile_off[c] + ((int64_t)(chrom_off[c + 1] - chrom_off[c]) + 7) / 8;
+  for (int c = 0; c < n_chrom; ++c) tile_off[c + 1] = tile_off[c] + ((int64_t)(chrom_off[c + 1] - chrom_off[c]) + 15) / 16;
   p->n_words = tile_off[n_chrom];
+  for (int c = 0; c < n_chrom; ++c) p->max_words = std::max(p->max_words, tile_off[c + 1] - tile_off[c]);
   p->c0 = std::log(T[0]);   // log(1 - t): into normal from normal
   p->c1 = std::log(T[3]);   // log(t / 2): into a CNV state from normal (T[3] == T[6])
   bool symmetric = (T[3] == T[6]);
@@ -984,10 +1077,12 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
         for (int64_t i = 0; i < m; ++i) pos[1 + i] = start[lo + i];
         pos[m + 1] = (int32_t)((double)end[hi - 1] + 2 * expected_cnv_length);
         fill_log_transitions(T, expected_cnv_length, pos.data(), m + 2, lt9.data());
-        double* o = lt3.data() + (size_t)(lo + c) * 3;
+        double* o = lt3.data() + (size_t)(lo + c) * 8;
         for (int64_t g = 0; g <= m; ++g) {
           const double* q = lt9.data() + g * 9;
-          o[g * 3 + 0] = q[1]; o[g * 3 + 1] = q[4]; o[g * 3 + 2] = q[5];
+          // quad lane 0 and 3: state 0 (A, A); lane 1: state 1 (B, C); lane 2: state 2 (C, B)
+          o[g * 8 + 0] = q[1]; o[g * 8 + 1] = q[2]; o[g * 8 + 2] = q[4]; o[g * 8 + 3] = q[5];
+          o[g * 8 + 4] = q[7]; o[g * 8 + 5] = q[8]; o[g * 8 + 6] = q[1]; o[g * 8 + 7] = q[2];
           if (std::memcmp(&q[1], &q[2], 8) || std::memcmp(&q[4], &q[8], 8) || std::memcmp(&q[5], &q[7], 8) ||
               std::memcmp(&q[0], &p->c0, 8) || std::memcmp(&q[3], &p->c1, 8) || std::memcmp(&q[6], &p->c1, 8))
             bad[tid] = 1;
@@ -1045,7 +1140,8 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes ? bytes : 1) != hipSuccess) ok = false; };
   A((void**)&b->d_loglik, (size_t)E * 3 * S * 8);
   A((void**)&b->d_path, (size_t)E * S);
-  A((void**)&b->d_bp, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 8);
+  A((void**)&b->d_bp, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4 * 4);
+  A((void**)&b->d_ppath, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4);
   A((void**)&b->d_consts, (size_t)9 * S * 8);
   A((void**)&b->d_cflags, (size_t)3 * S * 4);
   A((void**)&b->d_counts, (size_t)S * std::max<int64_t>(C, 1) * 4);
@@ -1057,6 +1153,44 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     ed_batch_destroy(b);
     return ed_fail(ED_ERR_NOMEM, "ed_batch_create: device allocation failed (E=%lld S=%lld)", (long long)E, (long long)S);
   }
+  {
+    // Pack chromosomes into Viterbi jobs (longest-processing-time greedy).  Few waves (batch smaller than
+    // the chip): as few jobs as the longest chromosome allows, so that each wave runs alone on a SIMD.
+    // Many waves: one job per chromosome (the batch is throughput-bound and more waves hide more latency).
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, plan->device));
+    const int64_t simds = (int64_t)prop.multiProcessorCount * 4;
+    const int64_t slots = (S + kVitChains - 1) / kVitChains;   // waves per job
+    std::vector<int> order;
+    int64_t total = 0, longest = 0;
+    for (int c = 0; c < (int)C; ++c) {
+      const int64_t mc = plan->chrom_off[c + 1] - plan->chrom_off[c];
+      if (mc > 0) { order.push_back(c); total += mc; longest = std::max(longest, mc); }
+    }
+    std::sort(order.begin(), order.end(), [&](int a, int bb) {
+      return plan->chrom_off[a + 1] - plan->chrom_off[a] > plan->chrom_off[bb + 1] - plan->chrom_off[bb]; });
+    int64_t nj = order.size();
+    if (longest > 0) {
+      const int64_t min_jobs = (total + longest - 1) / longest;
+      if (simds / std::max<int64_t>(slots, 1) >= min_jobs) nj = std::min<int64_t>(nj, min_jobs);
+    }
+    nj = std::max<int64_t>(nj, 1);
+    std::vector<std::vector<int>> jobs((size_t)nj);
+    std::vector<int64_t> load((size_t)nj, 0);
+    for (int c : order) {
+      size_t best = 0;
+      for (size_t k = 1; k < jobs.size(); ++k) if (load[k] < load[best]) best = k;
+      jobs[best].push_back(c);
+      load[best] += plan->chrom_off[c + 1] - plan->chrom_off[c];
+    }
+    std::vector<int32_t> joff(1, 0), jchr;
+    for (auto& jb : jobs) { for (int c : jb) jchr.push_back(c); joff.push_back((int32_t)jchr.size()); }
+    b->n_jobs = (int32_t)jobs.size();
+    HIP_TRY(hipMalloc((void**)&b->d_job_off, joff.size() * 4));
+    HIP_TRY(hipMalloc((void**)&b->d_job_chrom, std::max<size_t>(jchr.size(), 1) * 4));
+    HIP_TRY(hipMemcpy(b->d_job_off, joff.data(), joff.size() * 4, hipMemcpyHostToDevice));
+    if (!jchr.empty()) HIP_TRY(hipMemcpy(b->d_job_chrom, jchr.data(), jchr.size() * 4, hipMemcpyHostToDevice));
+  }
   for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
   *batch = b;
   return ED_OK;
@@ -1065,7 +1199,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
 ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
-  void* ptrs[] = {b->d_fit_partial, b->d_fit_eta, b->d_fit_lam, b->d_fit_done, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_ppath, b->d_fit_partial, b->d_fit_eta, b->d_fit_lam, b->d_fit_done, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -1097,10 +1231,14 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
     hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((cells + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells))), dim3(kEmitBlock), 0, st,
                        d_test, d_ref, b->d_consts, b->d_cflags, E, S, b->d_loglik, b->d_nerr);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
+  HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));   // empty chromosomes: no calls
   if (C > 0 && cells > 0)
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave), 0, st,
-                       b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp, b->d_path,
-                       b->d_counts);
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)b->n_jobs), dim3(kWave), 0, st,
+                       b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp, b->d_ppath,
+                       b->d_counts, b->d_job_off, b->d_job_chrom);
+  if (C > 0 && cells > 0 && p->max_words > 0)
+    hipLaunchKernelGGL(k_path_expand, dim3((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)C), dim3(256),
+                       0, st, b->d_ppath, p->d_chrom_off, p->d_tile_off, S, b->d_path);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, b->d_counts, (C > 0 && cells > 0) ? S * C : 0,
                      b->d_offsets, b->d_total);
