@@ -62,6 +62,66 @@ __constant__ const double k_lopx[21] = {
     -3.7581977830387938294437434651e-14, 5.1107345870861673561462339876e-15,  -7.0722150011433276578323272272e-16,
     9.7089758328248469219003866867e-17,  -1.3492637457521938883731579510e-17, 1.8657327910677296608121390705e-18};
 
+// ---- correctly rounded division without the scaling / fix-up stages ----------------------------
+// a/b as hipcc lowers it is  v_div_scale x2, v_rcp, 2 Newton steps, multiply, residual, v_div_fmas,
+// v_div_fixup (11 instructions).  The scale and fix-up stages only matter when an operand or the
+// quotient leaves the normal range (or is 0/inf/NaN in the divisor).  Where the caller guarantees
+//     b finite, normal, 2^-900 < |b| < 2^900;  a finite (zero allowed), |a/b| normal or zero
+// the remaining 8 instructions produce the same correctly rounded quotient (checked bit for bit against
+// '/' on the device and against the host in tests/test_gpu_parity.py::test_fast_division_is_exact).
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = a * r;
+  const double rem = __builtin_fma(-b, q, a);
+  return __builtin_fma(rem, r, q);
+}
+
+// ed_pexp(x) for |x| < ln2/2 only: there the argument reduction of ed_pexp is the identity (k = 0,
+// r = x exactly, both scale factors 2^0), so skipping it yields the same bits.
+__device__ __forceinline__ double pexp_small(double x)
+{
+  const double c[ED_PM_EXP_NC] = ED_PM_EXP_COEFFS;
+  double q = c[ED_PM_EXP_NC - 1];
+#pragma unroll
+  for (int i = ED_PM_EXP_NC - 2; i >= 0; --i) q = ed_pm_fma(q, x, c[i]);
+  return 1.0 + ed_pm_fma(x * x, q, x);
+}
+
+// ed_plog(x) for normal positive finite x, with the in-range division: same bits as ed_plog.
+__device__ __forceinline__ double plog_pos(double x)
+{
+  const double c[ED_PM_LOG_NC] = ED_PM_LOG_COEFFS;
+  const uint64_t u = ed_pm_bits(x);
+  int k = (int)(u >> 52) - 1023;
+  double m = ed_pm_from_bits((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+  if (m > ED_PM_SQRT2) { m = m * 0.5; k += 1; }
+  const double f = m - 1.0;
+  const double s = fdiv(f, 2.0 + f);
+  const double z = s * s;
+  double g = c[ED_PM_LOG_NC - 1];
+#pragma unroll
+  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma(g, z, c[i]);
+  const double R = z * g;
+  const double hfsq = (0.5 * f) * f;
+  const double dk = (double)k;
+  const double w = ed_pm_fma(s, hfsq + R, dk * ED_PM_LN2_LO);
+  const double v = f - (hfsq - w);
+  return ed_pm_fma(dk, ED_PM_LN2_HI, v);
+}
+
+// ed_plog with the fast path taken whenever x is a normal positive finite number (the cold generic
+// definition handles zero, subnormals, inf, NaN); same bits either way.
+__device__ __forceinline__ double plog_fast(double x)
+{
+  if (x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308) return plog_pos(x);
+  return ed_plog(x);
+}
+
 // Clenshaw recurrence on [-1,1]; the argument map ((2x+1)-1)/2 is kept because it is not an identity
 // in binary64 (reference src/VP_gamma.c:45-46).
 template <int ORDER>
@@ -83,6 +143,20 @@ __device__ __forceinline__ double clenshaw(const double* __restrict__ c, double 
 __device__ __forceinline__ double lngamma_lanczos(double x)
 {
   x -= 1.0;
+  if (x < 0x1p900) {   // every quotient below is in fdiv's range (x + k >= 0.5)
+    double Ag = 0.99999999999980993227684700473478;
+    Ag += fdiv(676.520368121885098567009190444019, x + 1.0);
+    Ag += fdiv(-1259.13921672240287047156078755283, x + 2.0);
+    Ag += fdiv(771.3234287776530788486528258894, x + 3.0);
+    Ag += fdiv(-176.61502916214059906584551354, x + 4.0);
+    Ag += fdiv(12.507343278686904814458936853, x + 5.0);
+    Ag += fdiv(-0.13857109526572011689554707, x + 6.0);
+    Ag += fdiv(9.984369578019570859563e-6, x + 7.0);
+    Ag += fdiv(1.50563273514931155834e-7, x + 8.0);
+    const double term1 = (x + 0.5) * plog_pos(fdiv(x + 7.5, EDSF_M_E));
+    const double term2 = EDSF_LOGROOT2PI + plog_fast(Ag);
+    return term1 + (term2 - 7.0);
+  }
   double Ag = 0.99999999999980993227684700473478;
   Ag += 676.520368121885098567009190444019 / (x + 1.0);
   Ag += -1259.13921672240287047156078755283 / (x + 2.0);
@@ -152,15 +226,15 @@ __device__ __forceinline__ double lngamma_pos(double x, bool zform)
 __device__ __forceinline__ double gammastar_large(double x)
 {
   if (x < 1.0 / EDSF_ROOT4_EPS) {
-    const double y = 1.0 / (x * x);
+    const double y = fdiv(1.0, x * x);   // 10 <= x < 8192
     const double c0 = 1.0 / 12.0, c1 = -1.0 / 360.0, c2 = 1.0 / 1260.0, c3 = -1.0 / 1680.0, c4 = 1.0 / 1188.0,
                  c5 = -691.0 / 360360.0, c6 = 1.0 / 156.0, c7 = -3617.0 / 122400.0;
     const double ser = c0 + y * (c1 + y * (c2 + y * (c3 + y * (c4 + y * (c5 + y * (c6 + y * c7))))));
-    return ed_pexp(ser / x);
+    return pexp_small(fdiv(ser, x));   // 0 < ser/x < 0.0084
   }
   if (x < 1.0 / EDSF_DBL_EPS) {
-    const double xi = 1.0 / x;
-    return 1.0 + xi / 12.0 * (1.0 + xi / 24.0 * (1.0 - xi * (139.0 / 180.0 + 571.0 / 8640.0 * xi)));
+    const double xi = fdiv(1.0, x);   // 8192 <= x < 4.6e15
+    return 1.0 + fdiv(xi, 12.0) * (1.0 + fdiv(xi, 24.0) * (1.0 - xi * (139.0 / 180.0 + 571.0 / 8640.0 * xi)));
   }
   return 1.0;
 }
@@ -195,7 +269,7 @@ __device__ __forceinline__ double log1plusx_ratio(double x)
     const double t = c5 + x * (c6 + x * (c7 + x * (c8 + x * c9)));
     return x * (1.0 + x * (c1 + x * (c2 + x * (c3 + x * (c4 + x * t)))));
   }
-  const double t = 0.5 * (8.0 * x + 1.0) / (x + 2.0);
+  const double t = fdiv(0.5 * (8.0 * x + 1.0), x + 2.0);
   return x * clenshaw<20>(k_lopx, t);
 }
 
@@ -232,9 +306,10 @@ __device__ __forceinline__ double lnbeta_ratio(double mn, double mx, double rat)
   const double gsb = gammastar_pos(mx);
   const double gsxy = gammastar_pos(mn + mx);
   const double lnopr = log1plusx_ratio(rat);
-  const double lnpre = ed_plog(((gsa * gsb) / gsxy * EDSF_M_SQRT2) * EDSF_M_SQRTPI);
-  const double t1 = mn * ed_plog(rat);
-  const double t2 = 0.5 * ed_plog(mn);
+  // Gamma* of a positive double lies in (0.9, 2e161): product and quotient stay in fdiv's range
+  const double lnpre = plog_fast((fdiv(gsa * gsb, gsxy) * EDSF_M_SQRT2) * EDSF_M_SQRTPI);
+  const double t1 = mn * plog_fast(rat);
+  const double t2 = 0.5 * plog_fast(mn);
   const double t3 = ((mn + mx) - 0.5) * lnopr;
   return lnpre + ((t1 - t2) - t3);
 }

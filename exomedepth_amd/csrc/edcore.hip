@@ -815,6 +815,9 @@ __global__ void k_eval_sf(int which, int64_t n, const double* __restrict__ x, co
     case 5: r = ed_psin_0pi(x[i]); break;
     case 6: { double a, b; edfit::digamma_trigamma(x[i], a, b); r = a; } break;
     case 7: { double a, b; edfit::digamma_trigamma(x[i], a, b); r = b; } break;
+    case 8: r = edsf::fdiv(x[i], y[i]); break;
+    case 9: r = edsf::pexp_small(x[i]); break;
+    case 10: r = edsf::plog_fast(x[i]); break;
     default: r = ed_pm_nan();
   }
   out[i] = r;

@@ -153,7 +153,8 @@ int ed_synchronize(void* stream);
 
 /* Element-wise evaluation of the device special functions on host arrays (used by the parity tests
  * to compare the device arithmetic with the checker bit for bit).
- * which: 0 lnbeta(x,y)  1 portable log(x)  2 portable exp(x)  3 sqrt(x)  4 x/y  5 portable sin(x) on [0,pi] */
+ * which: 0 lnbeta(x,y)  1 portable log(x)  2 portable exp(x)  3 sqrt(x)  4 x/y  5 portable sin(x) on [0,pi]
+ *        6 digamma(x)  7 trigamma(x)  8 in-range exact division x/y  9 exp for |x| < ln2/2  10 log, fast path */
 int ed_eval_sf(int which, int64_t n, const double* x, const double* y, double* out);
 
 #ifdef __cplusplus

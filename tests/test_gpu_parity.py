@@ -46,6 +46,37 @@ def test_ieee_div_sqrt_bit_exact(edlib):
     assert np.array_equal(bits(eval_sf(edlib, 4, tiny, np.full(4096, 3.0))), bits(tiny / 3.0))
 
 
+def test_fast_division_is_exact(edlib, oracle):
+    """The kernels replace '/' by an 8-instruction sequence wherever operands are known to be in range
+    (ed_sf_dev.hpp: fdiv); it must give the correctly rounded quotient, i.e. the host's."""
+    rng = np.random.default_rng(14)
+    n = 1 << 22
+    for lo, hi in ((-30, 30), (-300, 300), (-2, 2)):   # contract: 2^-900 < |b| < 2^900, quotient normal
+        a = np.exp(rng.uniform(lo, hi, n)) * rng.choice([-1.0, 1.0], n)
+        b = np.exp(rng.uniform(lo, hi, n)) * rng.choice([-1.0, 1.0], n)
+        got = eval_sf(edlib, 8, a, b)
+        bad = bits(got) != bits(a / b)
+        assert not bad.any(), (int(bad.sum()), a[bad][:3], b[bad][:3], got[bad][:3], (a / b)[bad][:3])
+    # the shapes the kernels actually produce: constants over x+k, 1/(x*x), ser/x, f/(2+f), a = 0
+    x = rng.uniform(0.5, 5000, n)
+    for c in (676.520368121885098567009190444019, 1.50563273514931155834e-7, 1.0, -0.13857109526572011689554707):
+        assert np.array_equal(bits(eval_sf(edlib, 8, np.full(n, c), x)), bits(c / x))
+    assert np.array_equal(bits(eval_sf(edlib, 8, x + 7.5, np.full(n, np.e))), bits((x + 7.5) / np.e))
+    f = rng.uniform(-0.2929, 0.4143, n)
+    assert np.array_equal(bits(eval_sf(edlib, 8, f, 2.0 + f)), bits(f / (2.0 + f)))
+    assert np.array_equal(bits(eval_sf(edlib, 8, np.zeros(8), np.arange(1.0, 9.0))), bits(np.zeros(8)))
+    ints = rng.integers(1, 1 << 26, n).astype(np.float64)
+    assert np.array_equal(bits(eval_sf(edlib, 8, ints, np.roll(ints, 1))), bits(ints / np.roll(ints, 1)))
+    # exp / log fast paths equal the portable definitions bit for bit
+    t = rng.uniform(-0.3465, 0.3465, n)
+    assert np.array_equal(bits(eval_sf(edlib, 9, t)), bits(oracle.pexp(t)))
+    t = np.concatenate([rng.uniform(0, 0.0085, n), [0.0]])
+    assert np.array_equal(bits(eval_sf(edlib, 9, t)), bits(oracle.pexp(t)))
+    z = np.concatenate([np.exp(rng.uniform(-708, 709, n)), [0.0, 5e-324, 1e-310, np.inf, np.nan, 2.2250738585072014e-308]])
+    got, exp = eval_sf(edlib, 10, z), oracle.plog(z)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(bits(got[~np.isnan(got)]), bits(exp[~np.isnan(exp)]))
+
+
 def test_portable_log_exp_sin_bit_exact(edlib, oracle):
     rng = np.random.default_rng(12)
     n = 1 << 20
