@@ -15,18 +15,50 @@
 
 namespace edfit {
 
+// Reciprocal and logarithm for the fit.  Nothing here has to match the checker bit for bit (the fit is
+// compared by tolerance), so the reciprocal is v_rcp_f64 + two Newton steps (~1 ulp) instead of an IEEE
+// division, and the logarithm is ed_plog's algorithm on top of that reciprocal.
+__device__ __forceinline__ double frcp(double b)
+{
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
+__device__ __forceinline__ double flog(double x)   // x normal, positive, finite
+{
+  const double c[ED_PM_LOG_NC] = ED_PM_LOG_COEFFS;
+  const uint64_t u = ed_pm_bits(x);
+  int k = (int)(u >> 52) - 1023;
+  double m = ed_pm_from_bits((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+  if (m > ED_PM_SQRT2) { m = m * 0.5; k += 1; }
+  const double f = m - 1.0;
+  const double s = f * frcp(2.0 + f);
+  const double z = s * s;
+  double g = c[ED_PM_LOG_NC - 1];
+#pragma unroll
+  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = __builtin_fma(g, z, c[i]);
+  const double hfsq = (0.5 * f) * f;
+  const double dk = (double)k;
+  const double w = __builtin_fma(s, hfsq + z * g, dk * ED_PM_LN2_LO);
+  return __builtin_fma(dk, ED_PM_LN2_HI, f - (hfsq - w));
+}
+
 // psi(x) and psi'(x) for x > 0: upward recurrence to x >= 10, then the asymptotic (Stirling) series
-// with 7 Bernoulli terms (truncation < 2e-16 relative at x = 10).
-__device__ __forceinline__ void digamma_trigamma(double x, double& psi, double& psi1)
+// with 7 Bernoulli terms (truncation < 2e-16 relative at x = 10).  psi_nolog leaves the ln x term to
+// the caller, who can merge the logarithms of several arguments into one (ln a - ln b = ln(a/b)).
+__device__ __forceinline__ void digamma_trigamma_nolog(double x, double& xs, double& psi_rest, double& psi1)
 {
   double s0 = 0.0, s1 = 0.0;
   while (x < 10.0) {   // divergent only for small shape parameters (high dispersion, low counts)
-    const double r = 1.0 / x;
+    const double r = frcp(x);
     s0 += r;
     s1 = __builtin_fma(r, r, s1);
     x += 1.0;
   }
-  const double r = 1.0 / x;
+  const double r = frcp(x);
   const double w = r * r;
   // psi(x)  = ln x - 1/(2x) - sum_k B_2k / (2k x^2k)
   double p = 1.0 / 12.0;                       // B14/14
@@ -36,7 +68,8 @@ __device__ __forceinline__ void digamma_trigamma(double x, double& psi, double& 
   p = __builtin_fma(p, w, 1.0 / 252.0);        // B6/6
   p = __builtin_fma(p, w, -1.0 / 120.0);       // B4/4
   p = __builtin_fma(p, w, 1.0 / 12.0);         // B2/2
-  psi = (ed_plog(x) - 0.5 * r) - p * w - s0;
+  psi_rest = (-0.5 * r - p * w) - s0;          // psi(x_original) = ln(xs) + psi_rest
+  xs = x;
   // psi'(x) = 1/x + 1/(2x^2) + sum_k B_2k / x^(2k+1)
   double q = 7.0 / 6.0;                        // B14
   q = __builtin_fma(q, w, -691.0 / 2730.0);    // B12
@@ -48,6 +81,13 @@ __device__ __forceinline__ void digamma_trigamma(double x, double& psi, double& 
   psi1 = __builtin_fma(q * w, r, __builtin_fma(0.5, w, r)) + s1;
 }
 
+__device__ __forceinline__ void digamma_trigamma(double x, double& psi, double& psi1)
+{
+  double xs, rest;
+  digamma_trigamma_nolog(x, xs, rest, psi1);
+  psi = flog(xs) + rest;
+}
+
 // accumulators of one sample: gradient and Hessian of the log-likelihood with respect to (a, b),
 // without the per-sample constant terms (those are added once per sample in the update kernel)
 struct Acc {
@@ -57,12 +97,14 @@ struct Acc {
 __device__ __forceinline__ void accumulate_cell(Acc& acc, double a, double b, double th, int y, int n)
 {
   if (n <= 0) return;   // lbeta(a+0, b+0) - lbeta(a, b) = 0: the cell carries no information
-  double p1, q1, p2, q2, p3, q3;
-  digamma_trigamma(a + (double)y, p1, q1);
-  digamma_trigamma(b + (double)(n - y), p2, q2);
-  digamma_trigamma(th + (double)n, p3, q3);
-  acc.ga += p1 - p3;
-  acc.gb += p2 - p3;
+  double x1, r1, q1, x2, r2, q2, x3, r3, q3;
+  digamma_trigamma_nolog(a + (double)y, x1, r1, q1);
+  digamma_trigamma_nolog(b + (double)(n - y), x2, r2, q2);
+  digamma_trigamma_nolog(th + (double)n, x3, r3, q3);
+  // psi(x1) - psi(x3) = ln(x1/x3) + (r1 - r3): two logarithms per cell instead of three
+  const double i3 = frcp(x3);
+  acc.ga += flog(x1 * i3) + (r1 - r3);
+  acc.gb += flog(x2 * i3) + (r2 - r3);
   acc.haa += q1 - q3;
   acc.hab -= q3;
   acc.hbb += q2 - q3;
