@@ -1,0 +1,14 @@
+"""Summarise a rocprofv3 counter_collection csv: per kernel of this library, mean counter value per launch."""
+import collections, csv, sys
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"]
+    if "anonymous namespace)::k_" not in k:
+        continue
+    name = k.split("::")[1].split("(")[0]
+    acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("kernel,counter,launches,mean_per_launch")
+for n in sorted(acc):
+    for c in sorted(acc[n]):
+        v = acc[n][c]
+        print("%s,%s,%d,%.6g" % (n, c, len(v), sum(v) / len(v)))
