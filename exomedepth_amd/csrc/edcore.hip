@@ -560,11 +560,12 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict_
 // state 0): when the state changes after a zero, `start` is set; when it changes after a non-zero
 // state a call (start, x-1, state, nexons) is pushed.  Quirks kept: `start` is NOT reset when one CNV
 // state switches directly to the other (the second call inherits the first one's start), and nexons
-// restarts only at a push.  The path is read 16 exons at a time; all-zero tiles are skipped.
+// restarts only at a push.  The path is read in its packed form (16 exons per 32-bit word, 8 words in
+// flight); all-normal words are skipped; a wave leaves once its chains have written all their calls.
 __global__ void __launch_bounds__(kWave)
-k_calls_fill(const uint8_t* __restrict__ path, const int32_t* __restrict__ chrom_off, int64_t S, int32_t C,
-             const int64_t* __restrict__ offsets, const int32_t* __restrict__ counts, ed_call* __restrict__ calls,
-             int64_t cap)
+k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chrom_off,
+             const int64_t* __restrict__ word_off, int64_t S, int32_t C, const int64_t* __restrict__ offsets,
+             const int32_t* __restrict__ counts, ed_call* __restrict__ calls, int64_t cap)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
   const int c = blockIdx.y;
@@ -573,50 +574,49 @@ k_calls_fill(const uint8_t* __restrict__ path, const int32_t* __restrict__ chrom
   const int64_t m = hi - lo;
   if (m <= 0) return;
   const int32_t todo = counts[s * C + c];
+  if (!__any(todo > 0)) return;
   const int64_t off = offsets[s * C + c];
-  const uint8_t* __restrict__ pth = path + lo * S + s;
-  constexpr int kT = 16;
+  const uint32_t* __restrict__ pp = ppath + word_off[c] * S + s;
+  const int64_t nw = (m + kVitTile - 1) / kVitTile;   // unused high bits of the last word are zero
+  constexpr int kW = 8;
   int64_t start = -1;
   int nexons = 0, prev = 0, k = 0;
-  // a wave leaves the loop as soon as all of its chains have written their calls
-  for (int64_t base = 0; base <= m && __any(k < todo); base += kT) {
-    unsigned b[kT];
-    unsigned any = 0;
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      const int64_t x = base + t;
-      b[t] = (x < m) ? pth[x * S] : 0u;
-      any |= b[t];
-    }
-    if ((any | (unsigned)prev) == 0) continue;
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      const int64_t x = base + t;
-      if (x > m) break;
-      const int cur = (int)b[t];
-      if (prev != cur) {
-        if (prev == 0) {
-          start = x;
-        } else {
-          const int64_t r = off + k;
-          if (r < cap) {
-            ed_call rec;
-            rec.sample = (int32_t)s;
-            rec.chrom = c;
-            rec.start_exon = (int32_t)(lo + start);
-            rec.end_exon = (int32_t)(lo + x - 1);
-            rec.type = prev;
-            rec.nexons = nexons;
-            calls[r] = rec;
-          }
-          ++k;
-          nexons = 0;
+  auto step = [&](int cur, int64_t x) {
+    if (prev != cur) {
+      if (prev == 0) {
+        start = x;
+      } else {
+        const int64_t r = off + k;
+        if (r < cap) {
+          ed_call rec;
+          rec.sample = (int32_t)s;
+          rec.chrom = c;
+          rec.start_exon = (int32_t)(lo + start);
+          rec.end_exon = (int32_t)(lo + x - 1);
+          rec.type = prev;
+          rec.nexons = nexons;
+          calls[r] = rec;
         }
+        ++k;
+        nexons = 0;
       }
-      if (cur != 0) ++nexons;
-      prev = cur;
+    }
+    if (cur != 0) ++nexons;
+    prev = cur;
+  };
+  for (int64_t wb = 0; wb < nw && __any(k < todo); wb += kW) {
+    uint32_t w[kW];
+#pragma unroll
+    for (int t = 0; t < kW; ++t) w[t] = (wb + t < nw) ? pp[(wb + t) * S] : 0u;
+#pragma unroll
+    for (int t = 0; t < kW; ++t) {
+      if ((w[t] | (uint32_t)prev) == 0) continue;
+      const int64_t x0 = (wb + t) * kVitTile;
+#pragma unroll
+      for (int q = 0; q < kVitTile; ++q) step((int)((w[t] >> (2 * q)) & 3), x0 + q);
     }
   }
+  if (prev != 0 && k < todo) step(0, m);   // the dummy last observation closes a run that reaches the end
 }
 
 // Single chain with caller-supplied probabilities: the reference's C_hmm signature.
@@ -686,18 +686,51 @@ k_fit_moments(const int32_t* __restrict__ test, const int32_t* __restrict__ ref,
   o[0] = sy; o[S] = sn; o[2 * S] = syy; o[3 * S] = cnt; o[4 * S] = 0; o[5 * S] = 0;
 }
 
+// Sum the per-chunk partials of one quantity set for 64 samples with a 64 x kRedY thread block: thread
+// (lane, y) adds chunks y, y + kRedY, ... in order, then the kRedY strands are added in a fixed tree in
+// LDS.  The order never depends on timing, so the fit is reproducible run to run.
+constexpr int kRedY = 16;
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int64_t nchunk, int64_t S, int64_t s,
+                                                bool live, double (&out)[kFitQ], double (*lds)[kRedY][kWave])
+{
+  const int y = threadIdx.y, lane = threadIdx.x;
+  double acc[kFitQ];
+#pragma unroll
+  for (int q = 0; q < kFitQ; ++q) acc[q] = 0.0;
+  if (live) {
+    for (int64_t c = y; c < nchunk; c += kRedY) {
+      const double* o = partial + (c * kFitQ) * S + s;
+#pragma unroll
+      for (int q = 0; q < kFitQ; ++q) acc[q] += o[q * S];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kFitQ; ++q) lds[q][y][lane] = acc[q];
+  __syncthreads();
+  for (int h = kRedY / 2; h >= 1; h >>= 1) {
+    if (y < h) {
+#pragma unroll
+      for (int q = 0; q < kFitQ; ++q) lds[q][y][lane] += lds[q][y + h][lane];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < kFitQ; ++q) out[q] = lds[q][0][lane];
+}
+
 // method-of-moments start: p0 = sum y / sum n; phi0 from the Pearson statistic
 //   sum_e (y - n p)^2 / (n p q) ~ cnt + phi * sum_e (n - 1)
-__global__ void k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
-                            double* __restrict__ lam, int* __restrict__ done)
+__global__ void __launch_bounds__(kWave * kRedY)
+k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
+            double* __restrict__ lam, int* __restrict__ done)
 {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  double sy = 0, sn = 0, syy = 0, cnt = 0;
-  for (int64_t c = 0; c < nchunk; ++c) {
-    const double* o = partial + (c * kFitQ) * S + s;
-    sy += o[0]; sn += o[S]; syy += o[2 * S]; cnt += o[3 * S];
-  }
+  __shared__ double lds[kFitQ][kRedY][kWave];
+  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const bool live = s < S;
+  double tot[kFitQ];
+  reduce_partials(partial, nchunk, S, s, live, tot, lds);
+  if (!live || threadIdx.y != 0) return;
+  const double sy = tot[0], sn = tot[1], syy = tot[2], cnt = tot[3];
   double p = (sn > 0) ? sy / sn : 0.5;
   p = fmin(fmax(p, 1e-6), 1.0 - 1e-6);
   const double q = 1.0 - p;
@@ -739,17 +772,18 @@ k_fit_accum(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, i
 // One Newton step on (eta, lambda) = (logit p, log(a+b)); steps are capped, and a non-concave local
 // model falls back to a scaled gradient step.  `final_pass` marks passes over all exons: only those
 // may declare convergence.
-__global__ void k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
-                             double* __restrict__ lam, int* __restrict__ done, double tol, int final_pass)
+__global__ void __launch_bounds__(kWave * kRedY)
+k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
+             double* __restrict__ lam, int* __restrict__ done, double tol, int final_pass)
 {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  if (done[s]) return;
-  double ga = 0, gb = 0, haa = 0, hab = 0, hbb = 0, cnt = 0;
-  for (int64_t c = 0; c < nchunk; ++c) {
-    const double* o = partial + (c * kFitQ) * S + s;
-    ga += o[0]; gb += o[S]; haa += o[2 * S]; hab += o[3 * S]; hbb += o[4 * S]; cnt += o[5 * S];
-  }
+  __shared__ double lds[kFitQ][kRedY][kWave];
+  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const bool live = (s < S) && !done[s < S ? s : 0];
+  if (!__syncthreads_or(live ? 1 : 0)) return;   // the whole tile has converged
+  double tot[kFitQ];
+  reduce_partials(partial, nchunk, S, s, live, tot, lds);
+  if (!live || threadIdx.y != 0) return;
+  double ga = tot[0], gb = tot[1], haa = tot[2], hab = tot[3], hbb = tot[4], cnt = tot[5];
   const double th = ed_pexp(lam[s]);
   const double p = 1.0 / (1.0 + ed_pexp(-eta[s]));
   const double q = 1.0 - p;
@@ -1249,7 +1283,7 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
                      b->d_offsets, b->d_total);
   if (C > 0 && cells > 0)
     hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave), 0, st,
-                       b->d_path, p->d_chrom_off, S, C, b->d_offsets, b->d_counts, b->d_calls, b->calls_cap);
+                       b->d_ppath, p->d_chrom_off, p->d_tile_off, S, C, b->d_offsets, b->d_counts, b->d_calls, b->calls_cap);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));
   HIP_TRY(hipGetLastError());
   b->ran = true;
@@ -1276,22 +1310,23 @@ ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
   const dim3 grid((unsigned)((S + kWave - 1) / kWave), (unsigned)nblk), block(kWave, kFitSub);
   const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
+  const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // chunks that the strided passes do not touch must not contribute: every pass rewrites all partials
   hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, d_ref, E, S, 4, b->d_fit_partial);
-  hipLaunchKernelGGL(k_fit_start, g1, b1, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
+  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
                      b->d_fit_done);
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
   const int coarse = (E >= 64 * 16) ? 4 : 0;
   for (int it = 0; it < coarse; ++it) {
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, d_ref, E, S, 16, b->d_fit_eta, b->d_fit_lam,
                        b->d_fit_done, b->d_fit_partial);
-    hipLaunchKernelGGL(k_fit_update, g1, b1, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
                        b->d_fit_done, 1e-6, 0);
   }
   for (int it = 0; it < 6; ++it) {
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, d_ref, E, S, 1, b->d_fit_eta, b->d_fit_lam,
                        b->d_fit_done, b->d_fit_partial);
-    hipLaunchKernelGGL(k_fit_update, g1, b1, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
                        b->d_fit_done, 1e-6, 1);
   }
   hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, b->d_fit_eta, b->d_fit_lam, S, d_phi, d_expected);
