@@ -122,8 +122,8 @@ constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per workgr
 
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
-             const int* __restrict__ cflags, int64_t E, int64_t S, double* __restrict__ loglik,
-             unsigned long long* __restrict__ nerr)
+             const int* __restrict__ cflags, int64_t cell_begin, int64_t cell_end, int64_t S,
+             double* __restrict__ loglik, unsigned long long* __restrict__ nerr)
 {
   __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
   __shared__ double t_b[kEmitTasks];   // max (ratio route) or y
@@ -133,8 +133,8 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   const int lane = tid & 63;
   if (tid == 0) { n_front = 0; n_back = 0; }
   __syncthreads();
-  const int64_t ncell = E * S;
-  const int64_t cell0 = (int64_t)blockIdx.x * (kEmitBlock * kEmitCells) + tid;
+  const int64_t ncell = cell_end;   // this launch covers cells [cell_begin, cell_end): whole chromosomes
+  const int64_t cell0 = cell_begin + (int64_t)blockIdx.x * (kEmitBlock * kEmitCells) + tid;
   int slot[kEmitCells * 3];
   int nflag = 0;
   // ---- phase 1: classify and scatter the tasks ----
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(kWave)
 k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, double c0, double c1,
           const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off, int64_t S, int32_t C,
           uint32_t* __restrict__ bpq, uint32_t* __restrict__ ppath, int32_t* __restrict__ counts,
-          const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom)
+          const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom, int job_base)
 {
   const int lane = threadIdx.x;
   const int j = lane & 3;
@@ -373,7 +373,8 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   // A workgroup runs a JOB: one or more whole chromosomes, one after the other.  The host packs the
   // chromosomes into jobs of about the longest chromosome's length so that, when the batch has fewer
   // waves than the chip has SIMDs, every wave has a SIMD to itself and the makespan is one long chain.
-  for (int jc = job_off[blockIdx.y]; jc < job_off[blockIdx.y + 1]; ++jc) {
+  const int job = job_base + (int)blockIdx.y;
+  for (int jc = job_off[job]; jc < job_off[job + 1]; ++jc) {
   const int c = job_chrom[jc];
   const int64_t lo = chrom_off[c], hi = chrom_off[c + 1];
   const int64_t m = hi - lo;
@@ -888,6 +889,11 @@ struct ed_batch {
   int32_t* d_job_off = nullptr;  // [n_jobs + 1]
   int32_t* d_job_chrom = nullptr;  // chromosomes in job order
   int32_t n_jobs = 0;
+  std::vector<std::vector<int>> jobs;   // host copy: chromosomes of each Viterbi job
+  std::vector<int32_t> group_off;       // job ranges of the overlap groups
+  hipStream_t side = nullptr;           // second stream: Viterbi jobs overlap the emissions of later jobs
+  std::vector<hipEvent_t> job_ev;       // emissions of group g are complete
+  hipEvent_t join_ev = nullptr;
   double* d_consts = nullptr;
   int* d_cflags = nullptr;
   int32_t* d_counts = nullptr;
@@ -1193,38 +1199,41 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     return ed_fail(ED_ERR_NOMEM, "ed_batch_create: device allocation failed (E=%lld S=%lld)", (long long)E, (long long)S);
   }
   {
-    // Pack chromosomes into Viterbi jobs (longest-processing-time greedy).  Few waves (batch smaller than
-    // the chip): as few jobs as the longest chromosome allows, so that each wave runs alone on a SIMD.
-    // Many waves: one job per chromosome (the batch is throughput-bound and more waves hide more latency).
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, plan->device));
-    const int64_t simds = (int64_t)prop.multiProcessorCount * 4;
-    const int64_t slots = (S + kVitChains - 1) / kVitChains;   // waves per job
+    // Viterbi jobs: one chromosome each, longest first, cut into a few GROUPS.  ed_batch_run issues the
+    // emissions group by group; the Viterbi chains of a group start on a side stream as soon as that
+    // group's emissions are done and run underneath the (VALU-bound) emissions of the following groups.
+    // Groups shrink geometrically so that the last, exposed Viterbi launch only holds short chains.
     std::vector<int> order;
-    int64_t total = 0, longest = 0;
+    int64_t total = 0;
     for (int c = 0; c < (int)C; ++c) {
       const int64_t mc = plan->chrom_off[c + 1] - plan->chrom_off[c];
-      if (mc > 0) { order.push_back(c); total += mc; longest = std::max(longest, mc); }
+      if (mc > 0) { order.push_back(c); total += mc; }
     }
     std::sort(order.begin(), order.end(), [&](int a, int bb) {
-      return plan->chrom_off[a + 1] - plan->chrom_off[a] > plan->chrom_off[bb + 1] - plan->chrom_off[bb]; });
-    int64_t nj = order.size();
-    if (longest > 0) {
-      const int64_t min_jobs = (total + longest - 1) / longest;
-      if (simds / std::max<int64_t>(slots, 1) >= min_jobs) nj = std::min<int64_t>(nj, min_jobs);
+      const int64_t la = plan->chrom_off[a + 1] - plan->chrom_off[a], lb = plan->chrom_off[bb + 1] - plan->chrom_off[bb];
+      return la != lb ? la > lb : a < bb; });
+    std::vector<std::vector<int>> jobs;
+    for (int c : order) jobs.push_back(std::vector<int>(1, c));
+    const double cuts[] = {0.40, 0.72, 0.90, 1.0};   // cumulative exon fraction at the end of each group
+    b->group_off.assign(1, 0);
+    int64_t run = 0;
+    size_t gi = 0;
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      run += plan->chrom_off[jobs[k][0] + 1] - plan->chrom_off[jobs[k][0]];
+      while (gi < 3 && (double)run >= cuts[gi] * (double)total && k + 1 < jobs.size()) {
+        if ((int32_t)(k + 1) > b->group_off.back()) b->group_off.push_back((int32_t)(k + 1));
+        ++gi;
+      }
     }
-    nj = std::max<int64_t>(nj, 1);
-    std::vector<std::vector<int>> jobs((size_t)nj);
-    std::vector<int64_t> load((size_t)nj, 0);
-    for (int c : order) {
-      size_t best = 0;
-      for (size_t k = 1; k < jobs.size(); ++k) if (load[k] < load[best]) best = k;
-      jobs[best].push_back(c);
-      load[best] += plan->chrom_off[c + 1] - plan->chrom_off[c];
-    }
+    if (b->group_off.back() != (int32_t)jobs.size()) b->group_off.push_back((int32_t)jobs.size());
     std::vector<int32_t> joff(1, 0), jchr;
     for (auto& jb : jobs) { for (int c : jb) jchr.push_back(c); joff.push_back((int32_t)jchr.size()); }
     b->n_jobs = (int32_t)jobs.size();
+    b->jobs = jobs;
+    HIP_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    b->job_ev.resize(b->group_off.size());
+    for (auto& e : b->job_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void**)&b->d_job_off, joff.size() * 4));
     HIP_TRY(hipMalloc((void**)&b->d_job_chrom, std::max<size_t>(jchr.size(), 1) * 4));
     HIP_TRY(hipMemcpy(b->d_job_off, joff.data(), joff.size() * 4, hipMemcpyHostToDevice));
@@ -1241,6 +1250,9 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_ppath, b->d_fit_partial, b->d_fit_eta, b->d_fit_lam, b->d_fit_done, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
+  if (b->join_ev) (void)hipEventDestroy(b->join_ev);
+  if (b->side) (void)hipStreamDestroy(b->side);
   delete b;
 }
 
@@ -1266,15 +1278,28 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
                      b->d_consts, b->d_cflags);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int64_t cells = E * S;
-  if (cells > 0)
-    hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((cells + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells))), dim3(kEmitBlock), 0, st,
-                       d_test, d_ref, b->d_consts, b->d_cflags, E, S, b->d_loglik, b->d_nerr);
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
+  // Emissions are issued group by group (groups of whole chromosomes, longest chromosomes first); when a
+  // group's emissions are done its Viterbi chains start on the side stream and run underneath the
+  // VALU-bound emissions of the following groups.  Only the last group's (short) chains are exposed.
   HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));   // empty chromosomes: no calls
-  if (C > 0 && cells > 0)
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)b->n_jobs), dim3(kWave), 0, st,
-                       b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp, b->d_ppath,
-                       b->d_counts, b->d_job_off, b->d_job_chrom);
+  for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) {
+    const int j0 = b->group_off[g], j1 = b->group_off[g + 1];
+    for (int jb = j0; jb < j1; ++jb) {
+      for (int c : b->jobs[jb]) {
+        const int64_t cb = (int64_t)p->chrom_off[c] * S, ce = (int64_t)p->chrom_off[c + 1] * S;
+        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((ce - cb + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells))),
+                           dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, cb, ce, S, b->d_loglik, b->d_nerr);
+      }
+    }
+    HIP_TRY(hipEventRecord(b->job_ev[g], st));
+    HIP_TRY(hipStreamWaitEvent(b->side, b->job_ev[g], 0));
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
+                       b->side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
+                       b->d_ppath, b->d_counts, b->d_job_off, b->d_job_chrom, j0);
+  }
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));   // all emissions issued and done on the main stream
+  HIP_TRY(hipEventRecord(b->join_ev, b->side));
+  HIP_TRY(hipStreamWaitEvent(st, b->join_ev, 0));
   if (C > 0 && cells > 0 && p->max_words > 0)
     hipLaunchKernelGGL(k_path_expand, dim3((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)C), dim3(256),
                        0, st, b->d_ppath, p->d_chrom_off, p->d_tile_off, S, b->d_path);
