@@ -23,6 +23,15 @@ def oracle():
 @pytest.fixture(scope="session")
 def edlib():
     """The product library; GPU tests fail loudly if it is missing or no device is usable."""
+    # When PyTorch shares the process it must bring up its HIP runtime first, so that libedcore.so binds to
+    # the same libamdhip64 instead of loading a second copy (two runtimes in one process do not both see
+    # the device).  bench.py imports torch first for the same reason.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import exomedepth_amd
     from exomedepth_amd import _lib
     L = _lib.lib()
