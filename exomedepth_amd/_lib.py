@@ -17,6 +17,11 @@ class EdError(RuntimeError):
     pass
 
 
+class EdRefsetRow(C.Structure):
+    _fields_ = [("ref_index", C.c_int32), ("selected", C.c_int32), ("correlation", C.c_double), ("expected_BF", C.c_double),
+                ("phi", C.c_double), ("ratio_sd", C.c_double), ("mean_p", C.c_double), ("median_depth", C.c_double)]
+
+
 class EdCall(C.Structure):
     _fields_ = [("sample", C.c_int32), ("chrom", C.c_int32), ("start_exon", C.c_int32), ("end_exon", C.c_int32),
                 ("type", C.c_int32), ("nexons", C.c_int32)]
@@ -50,6 +55,7 @@ SYMBOLS = [
     ("ed_batch_copy_loglik", C.c_int, [_vp, _vp]),
     ("ed_batch_enable_timing", C.c_int, [_vp, C.c_int]),
     ("ed_batch_stage_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("ed_select_reference_set", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     ("ed_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
     ("ed_free", C.c_int, [_vp]),
     ("ed_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t]),

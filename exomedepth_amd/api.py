@@ -20,7 +20,7 @@ import sys
 import numpy as np
 
 from . import _lib
-from ._lib import EdCall, EdError, check, lib
+from ._lib import EdCall, EdError, EdRefsetRow, check, lib
 
 CALL_DTYPE = np.dtype([("sample", "<i4"), ("chrom", "<i4"), ("start_exon", "<i4"), ("end_exon", "<i4"),
                        ("type", "<i4"), ("nexons", "<i4")])
@@ -393,6 +393,47 @@ class ExomeDepth:
                           "reads.ratio": _signif(reads_observed / reads_expected, 3) if reads_expected else float("nan")})
         self.CNV_calls = calls
         return self
+
+
+REFSET_DTYPE = np.dtype([("ref_index", "<i4"), ("selected", "<i4"), ("correlation", "<f8"), ("expected_BF", "<f8"),
+                         ("phi", "<f8"), ("ratio_sd", "<f8"), ("mean_p", "<f8"), ("median_depth", "<f8")])
+assert REFSET_DTYPE.itemsize == C.sizeof(EdRefsetRow)
+
+
+def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_reduced=0, names=None):
+    """reference R/optimize_reference_set.R:53-148 (formula ~ 1, phi.bins = 1).
+
+    test_counts: (E,) ; reference_counts: (E, R) matrix, one column per candidate reference sample (host array,
+    or a torch CUDA int32 tensor of shape (E, R)).  Returns {'reference.choice': [...], 'summary.stats':
+    structured array (REFSET_DTYPE, sorted by decreasing correlation), 'n.bins': int}."""
+    keep = []
+    if hasattr(reference_counts, "shape") and len(reference_counts.shape) != 2:
+        raise ValueError("The reference sequence count data must be provided as a matrix")
+    E, R = int(reference_counts.shape[0]), int(reference_counts.shape[1])
+    if int(np.prod(np.shape(test_counts))) != E and not hasattr(test_counts, "data_ptr"):
+        raise ValueError("The number of rows of the reference matrix must match the length of the test count data\n")
+    if not hasattr(test_counts, "data_ptr"):
+        test_counts = _as_r_integer(np.asarray(test_counts))
+    if not hasattr(reference_counts, "data_ptr"):
+        reference_counts = _as_r_integer(np.asarray(reference_counts))
+    pt = _device_pointer(test_counts, np.int32, keep)
+    pr = _device_pointer(reference_counts, np.int32, keep)
+    bl = None
+    if bin_length is not None:
+        bl = _f64(bin_length)
+        if np.any(bl == 0):
+            z = int(np.sum(bl == 0))
+            raise ValueError("bin.length contains %d zero%s. This causes NAs in correlation computing. All bin lengths "
+                             "must be positive" % (z, "s" if z > 1 else ""))
+    rows = np.zeros(R, dtype=REFSET_DTYPE)
+    n_chosen = C.c_int32(0)
+    n_sel = C.c_int64(0)
+    check(lib().ed_select_reference_set(pt, pr, E, R, _ptr(bl) if bl is not None else None, int(n_bins_reduced),
+                                        _ptr(rows), C.byref(n_chosen), C.byref(n_sel), None))
+    if names is None:
+        names = ["X%d" % (i + 1) for i in range(R)]       # R/optimize_reference_set.R:76
+    choice = [names[int(i)] for i in rows["ref_index"][: n_chosen.value]]
+    return {"reference.choice": choice, "summary.stats": rows, "n.bins": int(n_sel.value)}
 
 
 def _signif(x, digits):

@@ -664,8 +664,8 @@ constexpr int kFitQ = 6;            // quantities per partial
 
 // moments for the starting point: sum y, sum n, sum y^2/n, #cells with n > 0
 __global__ void __launch_bounds__(kWave * kFitSub)
-k_fit_moments(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t E, int64_t S, int stride,
-              double* __restrict__ partial)
+k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t E,
+              int64_t S, int stride, double* __restrict__ partial)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
   const int sub = threadIdx.y;
@@ -675,7 +675,7 @@ k_fit_moments(const int32_t* __restrict__ test, const int32_t* __restrict__ ref,
   const int64_t e1 = min(e0 + kFitChunk / kFitSub, E);
   double sy = 0, sn = 0, syy = 0, cnt = 0;
   for (int64_t e = e0; e < e1; e += stride) {
-    const int y = test[e * S + s];
+    const int y = test[e * trs + s * tcs];   // (trs, tcs) = (S, 1): one column per sample; (1, 0): one shared column
     const int n = y + ref[e * S + s];
     if (n > 0) {
       sy += (double)y; sn += (double)n;
@@ -744,8 +744,8 @@ k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, doubl
 }
 
 __global__ void __launch_bounds__(kWave * kFitSub)
-k_fit_accum(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t E, int64_t S, int stride,
-            const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
+k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t E,
+            int64_t S, int stride, const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
             double* __restrict__ partial)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
@@ -761,7 +761,7 @@ k_fit_accum(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, i
   edfit::Acc acc = {0, 0, 0, 0, 0};
   double cnt = 0;
   for (int64_t e = e0; e < e1; e += stride) {
-    const int y = test[e * S + s];
+    const int y = test[e * trs + s * tcs];   // (trs, tcs) = (S, 1): one column per sample; (1, 0): one shared column
     const int n = y + ref[e * S + s];
     if (n > 0) cnt += 1.0;
     edfit::accumulate_cell(acc, a, b, th, y, n);
@@ -804,25 +804,52 @@ k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, doub
   const double h_ee = haa * ae * ae + 2.0 * hab * ae * be + hbb * be * be + (ga * a * q - gb * b * p) * (1.0 - 2.0 * p);
   const double h_el = haa * ae * a + hab * (ae * b + a * be) + hbb * be * b + ga * ae + gb * be;
   const double h_ll = haa * a * a + 2.0 * hab * a * b + hbb * b * b + ga * a + gb * b;
-  const double det = h_ee * h_ll - h_el * h_el;
-  double de, dl;
-  if (h_ee < 0.0 && det > 0.0) {
-    de = -(h_ll * g_e - h_el * g_l) / det;
-    dl = -(h_ee * g_l - h_el * g_e) / det;
+  // Dispersion coordinate of the Newton step.  lambda = log(a+b) is the better-conditioned coordinate for
+  // ordinary dispersions (one full pass fewer than psi), but for nearly binomial data (phi -> 0) the
+  // likelihood is exponentially flat in lambda and regular in psi = 1/(a+b) = phi/(1-phi), and a Newton
+  // iteration in lambda walks off into the flat region: below psi = 5e-5 the step is taken in psi.
+  // Chain rule:  d/dpsi = -th d/dlambda  =>  g_s = -th g_l,  h_es = -th h_el,  h_ss = th^2 (h_ll + g_l).
+  const double psi = 1.0 / th;
+  double de, ds;
+  if (psi >= 5e-5) {
+    const double det = h_ee * h_ll - h_el * h_el;
+    double dl;
+    if (h_ee < 0.0 && det > 0.0) {
+      de = -(h_ll * g_e - h_el * g_l) / det;
+      dl = -(h_ee * g_l - h_el * g_e) / det;
+    } else {   // not locally concave: scaled gradient step
+      de = g_e / (fabs(h_ee) + 1e-300);
+      dl = g_l / (fabs(h_ll) + fabs(h_el) + 1e-300);
+    }
+    dl = fmin(fmax(dl, -1.0), 1.0);
+    ds = psi * (ed_pexp(-dl) - 1.0);
   } else {
-    de = g_e / (fabs(h_ee) + 1e-300);
-    dl = g_l / (fabs(h_ll) + fabs(h_el) + 1e-300);
+    const double g_s = -th * g_l;
+    const double h_es = -th * h_el;
+    const double h_ss = th * th * (h_ll + g_l);
+    const double det = h_ee * h_ss - h_es * h_es;
+    if (h_ee < 0.0 && det > 0.0) {
+      de = -(h_ss * g_e - h_es * g_s) / det;
+      ds = -(h_ee * g_s - h_es * g_e) / det;
+    } else {
+      de = g_e / (fabs(h_ee) + 1e-300);
+      ds = g_s / (fabs(h_ss) + fabs(h_es) + 1e-300);
+    }
   }
   de = fmin(fmax(de, -1.0), 1.0);
-  dl = fmin(fmax(dl, -1.0), 1.0);
-  double ne = eta[s] + de, nl = lam[s] + dl;
-  nl = fmin(fmax(nl, -0.6931471805599453), 18.420680743952367);   // phi in [1e-8, 2/3]
-  ne = fmin(fmax(ne, -20.0), 20.0);
+  double npsi = psi + ds;
+  npsi = fmin(fmax(npsi, 0.1 * psi), 10.0 * psi);       // multiplicative trust region
+  // phi in [1e-6, 2/3].  Below phi ~ 1e-6 the model is numerically binomial: a + b > 1e6 and the digamma
+  // differences that make up the gradient cancel to noise, so the dispersion is not estimable in binary64.
+  npsi = fmin(fmax(npsi, 1e-6), 2.0);
+  const double ne = fmin(fmax(eta[s] + de, -20.0), 20.0);
   eta[s] = ne;
-  lam[s] = nl;
-  // Newton converges quadratically: once a step over ALL exons is below tol (1e-6), the error left after
-  // applying it is of order tol^2, far below the 1e-8 the fit is held to -- no confirming pass is needed.
-  if (final_pass && fabs(de) < tol && fabs(dl) < tol) done[s] = 1;
+  lam[s] = -ed_plog(npsi);
+  // Newton converges quadratically: once a step over ALL exons is below tol (1e-6, relative for psi), the
+  // error left after applying it is of order tol^2, far below the 1e-8 the fit is held to -- no
+  // confirming pass is needed.  A sample pinned at the lower bound of psi has also converged.
+  const bool at_floor = (npsi <= 1e-6 && psi <= 1.0000001e-6);
+  if (final_pass && ((fabs(de) < tol && fabs(npsi - psi) < tol * psi) || at_floor)) done[s] = 1;
 }
 
 __global__ void k_fit_finish(const double* __restrict__ eta, const double* __restrict__ lam, int64_t S,
@@ -901,11 +928,7 @@ struct ed_batch {
   int64_t* d_total = nullptr;
   unsigned long long* d_nerr = nullptr;
   ed_call* d_calls = nullptr;
-  double* d_fit_partial = nullptr;   // [nchunk][6][S]
-  double* d_fit_eta = nullptr;
-  double* d_fit_lam = nullptr;
-  int* d_fit_done = nullptr;
-  int64_t fit_nchunk = 0;
+  struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
   int64_t calls_cap = 0;
   hipStream_t stream = nullptr;
   bool ran = false;
@@ -1244,10 +1267,13 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   return ED_OK;
 }
 
+static void fitwork_free(struct FitWork* w);
+
 ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_ppath, b->d_fit_partial, b->d_fit_eta, b->d_fit_lam, b->d_fit_done, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  fitwork_free(b->fitw);
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -1316,6 +1342,63 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
   return ED_OK;
 }
 
+// workspace of the column-wise beta-binomial fit (shared by ed_batch_fit and ed_select_reference_set)
+struct FitWork {
+  double* partial = nullptr;   // [nchunk][kFitQ][S]
+  double* eta = nullptr;
+  double* lam = nullptr;
+  int* done = nullptr;
+  int64_t nchunk = 0, S = 0;
+  int alloc(int64_t E, int64_t S_)
+  {
+    release();
+    S = S_;
+    nchunk = ((E + kFitChunk - 1) / kFitChunk) * kFitSub;
+    HIP_TRY(hipMalloc((void**)&partial, (size_t)std::max<int64_t>(nchunk, 1) * kFitQ * S * 8));
+    HIP_TRY(hipMalloc((void**)&eta, (size_t)S * 8));
+    HIP_TRY(hipMalloc((void**)&lam, (size_t)S * 8));
+    HIP_TRY(hipMalloc((void**)&done, (size_t)S * 4));
+    return ED_OK;
+  }
+  void release()
+  {
+    void* ptrs[] = {partial, eta, lam, done};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    partial = eta = lam = nullptr; done = nullptr;
+  }
+};
+
+static void fitwork_free(FitWork* w)
+{
+  if (w) { w->release(); delete w; }
+}
+
+// Fit S columns: column s has test counts test[e*trs + s*tcs] and reference counts ref[e*S + s], e < E.
+static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t E,
+                       int64_t S, double* d_phi, double* d_expected, hipStream_t st)
+{
+  const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
+  const dim3 grid((unsigned)((S + kWave - 1) / kWave), (unsigned)nblk), block(kWave, kFitSub);
+  const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
+  const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
+  // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
+  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, E, S, 4, w.partial);
+  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done);
+  // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
+  const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
+  for (int it = 0; it < coarse; ++it) {
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, E, S, 16, w.eta, w.lam, w.done, w.partial);
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done, 1e-6, 0);
+  }
+  for (int it = 0; it < 10; ++it) {   // converged columns skip their work; typically 3 passes do something
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, E, S, 1, w.eta, w.lam, w.done, w.partial);
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done, 1e-6, 1);
+  }
+  hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
+  HIP_TRY(hipGetLastError());
+  return ED_OK;
+}
+
 ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
                            void* stream_)
 {
@@ -1323,40 +1406,15 @@ ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_
   hipStream_t st = (hipStream_t)stream_;
   const int64_t E = b->plan->E, S = b->S;
   if (E <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_fit: no exons");
-  const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
-  if (!b->d_fit_partial) {
-    b->fit_nchunk = nblk * kFitSub;
-    HIP_TRY(hipMalloc((void**)&b->d_fit_partial, (size_t)b->fit_nchunk * kFitQ * S * 8));
-    HIP_TRY(hipMalloc((void**)&b->d_fit_eta, (size_t)S * 8));
-    HIP_TRY(hipMalloc((void**)&b->d_fit_lam, (size_t)S * 8));
-    HIP_TRY(hipMalloc((void**)&b->d_fit_done, (size_t)S * 4));
+  if (!b->fitw) {
+    b->fitw = new (std::nothrow) FitWork;
+    if (!b->fitw) return ed_fail(ED_ERR_NOMEM, "out of host memory");
+    if (int rc = b->fitw->alloc(E, S)) return rc;
   }
   b->stream = st;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
-  const dim3 grid((unsigned)((S + kWave - 1) / kWave), (unsigned)nblk), block(kWave, kFitSub);
-  const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
-  const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
-  // chunks that the strided passes do not touch must not contribute: every pass rewrites all partials
-  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, d_ref, E, S, 4, b->d_fit_partial);
-  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
-                     b->d_fit_done);
-  // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
-  const int coarse = (E >= 64 * 16) ? 4 : 0;
-  for (int it = 0; it < coarse; ++it) {
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, d_ref, E, S, 16, b->d_fit_eta, b->d_fit_lam,
-                       b->d_fit_done, b->d_fit_partial);
-    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
-                       b->d_fit_done, 1e-6, 0);
-  }
-  for (int it = 0; it < 6; ++it) {
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, d_ref, E, S, 1, b->d_fit_eta, b->d_fit_lam,
-                       b->d_fit_done, b->d_fit_partial);
-    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, b->d_fit_partial, b->fit_nchunk, S, b->d_fit_eta, b->d_fit_lam,
-                       b->d_fit_done, 1e-6, 1);
-  }
-  hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, b->d_fit_eta, b->d_fit_lam, S, d_phi, d_expected);
+  if (int rc = fit_columns(*b->fitw, d_test, S, 1, d_ref, E, S, d_phi, d_expected, st)) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[6], st));
-  HIP_TRY(hipGetLastError());
   b->have_fit_time = b->timing;
   return ED_OK;
 }
@@ -1435,3 +1493,5 @@ ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
   }
   return ED_OK;
 }
+
+#include "edrefset.inc"

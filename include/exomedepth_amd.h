@@ -143,6 +143,37 @@ int ed_batch_copy_loglik(ed_batch* batch, double* host_loglik /* [n_exons][3][n_
 int ed_batch_enable_timing(ed_batch* batch, int enable);
 int ed_batch_stage_ms(ed_batch* batch, float ms[5]);
 
+/* =====================================================================================
+ * 3. Reference-set optimisation (the "next" row of the path: select.reference.set)
+ * ===================================================================================== */
+
+/* One row of the reference's summary.stats data frame (R/optimize_reference_set.R:104-111), in order of
+ * decreasing correlation.  Fields the R loop never reaches after its early exit (:130) are NaN. */
+typedef struct {
+  int32_t ref_index;     /* column of the reference matrix (0-based) */
+  int32_t selected;      /* 1 on the row where expected.BF is maximal (:143-144) */
+  double correlation;    /* :100 */
+  double expected_BF;    /* :135-139, get.power.betabinom (R/tools.R:128-166) */
+  double phi;            /* :125 */
+  double ratio_sd;       /* :128 */
+  double mean_p;         /* :126 */
+  double median_depth;   /* :127 */
+} ed_refset_row;
+
+/* select.reference.set(test.counts, reference.counts, bin.length, n.bins.reduced), reference
+ * R/optimize_reference_set.R:53-148, with formula ~ 1 and phi.bins = 1 (its defaults).
+ *   d_test   DEVICE int32 [n_bins]
+ *   d_refs   DEVICE int32 [n_bins][n_refs]  (reference-minor; R's matrix is the transpose in memory)
+ *   bin_length  HOST double [n_bins] or NULL (= rep(1, n))        n_bins_reduced  0 = use all selected bins
+ *   rows     HOST out, n_refs entries sorted by decreasing correlation
+ *   n_chosen = which.max(expected.BF): reference.choice is rows[0 .. n_chosen-1].ref_index
+ *   n_selected_bins (optional) = "Number of selected bins" (:97)
+ * The R loop fits one beta-binomial model per prefix of the sorted references, sequentially; here all
+ * prefixes are fitted as one batch.  Synchronous (the result is host data). */
+int ed_select_reference_set(const int32_t* d_test, const int32_t* d_refs, int64_t n_bins, int64_t n_refs,
+                            const double* bin_length, int64_t n_bins_reduced, ed_refset_row* rows, int32_t* n_chosen,
+                            int64_t* n_selected_bins, void* stream);
+
 /* ---- utilities ---- */
 /* device memory through the library, for callers without a HIP binding (tests, R shim) */
 int ed_malloc(void** dptr, size_t bytes);

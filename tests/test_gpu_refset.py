@@ -1,0 +1,65 @@
+"""select.reference.set on the GPU against the CPU restatement of the R code (oracle/refset_oracle.py).
+Parity status: unpinned against the reference (the R code needs R, aod and VGAM); tolerance-level."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cohort(E, R, seed, depth=60.0, noise=(0.02, 0.35)):
+    """A test sample plus R candidate references of graded similarity: reference r carries a multiplicative
+    per-exon distortion whose size grows with r, so correlations are well separated."""
+    rng = np.random.default_rng(seed)
+    lam = rng.lognormal(np.log(depth), 0.7, E)
+    length = rng.integers(60, 600, E).astype(np.float64)
+    test = rng.poisson(lam * 1.0)
+    sig = np.linspace(noise[0], noise[1], R)[rng.permutation(R)]
+    refs = np.stack([rng.poisson(lam * rng.lognormal(0.0, s, E) * rng.uniform(0.7, 1.3)) for s in sig], axis=1)
+    return test.astype(np.int32), refs.astype(np.int32), length
+
+
+@pytest.mark.parametrize("E,R,reduced,use_len", [(6000, 10, 0, True), (9000, 7, 2500, False)])
+def test_select_reference_set_matches_the_restated_r_code(edlib, oracle, E, R, reduced, use_len):
+    from oracle import refset_oracle as ro
+    test, refs, length = _cohort(E, R, seed=100 + R)
+    bl = length if use_len else None
+    got = edlib.select_reference_set(test, refs, bin_length=bl, n_bins_reduced=reduced)
+    exp = ro.select_reference_set(test, refs, bin_length=bl, n_bins_reduced=reduced)
+    st = got["summary.stats"]
+    assert got["n.bins"] == exp["n_bins"]
+    assert np.array_equal(st["ref_index"], exp["order"])
+    assert np.allclose(st["correlation"], exp["correlations"], rtol=0, atol=1e-12)
+    for mine, theirs, tol in (("phi", "phi", 1e-7), ("mean_p", "mean_p", 1e-8), ("median_depth", "median_depth", 0.0),
+                              ("ratio_sd", "RatioSd", 1e-8), ("expected_BF", "expected_BF", 1e-7)):
+        a, b = st[mine], exp[theirs]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), mine
+        m = ~np.isnan(b)
+        assert np.all(np.abs(a[m] - b[m]) <= tol * np.abs(b[m])), (mine, a, b)
+    assert len(got["reference.choice"]) == exp["n_chosen"]
+    assert int(np.argmax(st["selected"])) == exp["n_chosen"] - 1 and st["selected"].sum() == 1
+    # the best-correlated references are the least distorted ones, and adding the worst ones does not pay
+    assert 1 <= exp["n_chosen"] <= R
+
+
+def test_select_reference_set_early_exit_and_guards(edlib, oracle):
+    from oracle import refset_oracle as ro
+    # many deep references: the test proportion drops below 0.05 and the R loop breaks (:130)
+    test, refs, _ = _cohort(5000, 30, seed=7, depth=40.0, noise=(0.05, 0.1))
+    got = edlib.select_reference_set(test, refs)
+    exp = ro.select_reference_set(test, refs)
+    st = got["summary.stats"]
+    assert np.array_equal(np.isnan(st["expected_BF"]), np.isnan(exp["expected_BF"]))
+    assert np.isnan(st["expected_BF"]).any() and np.array_equal(np.isnan(st["phi"]), np.isnan(exp["phi"]))
+    assert len(got["reference.choice"]) == exp["n_chosen"]
+    # coverage guard (:57-61): fewer than 5 bins with more than 2 reads -> first reference
+    got = edlib.select_reference_set(np.zeros(100, np.int32), refs[:100])
+    assert got["reference.choice"] == ["X1"]
+    with pytest.raises(ValueError, match="bin.length contains 1 zero"):
+        edlib.select_reference_set(test, refs, bin_length=np.r_[0.0, np.ones(4999)])
+
+
+def test_get_power_betabinom_known_properties(oracle):
+    from oracle import refset_oracle as ro
+    # reference R/tools.R:123-125 examples: positive when the alternative differs, exactly 0 when it does not
+    assert ro.get_power_betabinom(200, 0.1, 0.2, 0.6) > 1.0
+    assert abs(ro.get_power_betabinom(200, 0.1, 0.2, 0.2)) < 1e-12
