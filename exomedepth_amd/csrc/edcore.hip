@@ -426,11 +426,14 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
     }
 #pragma unroll
     for (int h = 0; h < kFwdTile / kVitTile; ++h) {
+      // all 16 log-transition rows of the word first (back-to-back LDS reads, one wait), then the chain
+      double2 lrow[kVitTile];
+#pragma unroll
+      for (int k = 0; k < kVitTile; ++k) lrow[k] = lds_lt[buf][h * kVitTile + k][j];
       uint32_t w = 0;
 #pragma unroll
       for (int k = 0; k < kVitTile; ++k) {
-        const double2 l = lds_lt[buf][h * kVitTile + k][j];
-        const unsigned fw = vit_step_q(v, ecur[h * kVitTile + k], t0, l.x, l.y);
+        const unsigned fw = vit_step_q(v, ecur[h * kVitTile + k], t0, lrow[k].x, lrow[k].y);
         w |= fw << (2 * k);
       }
       if (live) bpc[(t * (kFwdTile / kVitTile) + h) * wstride] = w;

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r01_d
+# Produces under gpurun_out/<tag>/: kernel stats of bench.py, and PMC summaries (separate passes, as the
+# counters do not fit one pass and must not be mixed with other trace domains).
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+export TMPDIR=/tmp
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python bench.py --steps 5 --warmup 1 --cpu-samples 0 > $OUT/bench_ks.log 2>&1
+grep -h '^{' $OUT/bench_ks.log > $OUT/bench_line.json
+python - "$OUT" <<'PY'
+import csv, sys
+out = sys.argv[1]
+rows = list(csv.reader(open(out + "/ks_kernel_stats.csv")))
+with open(out + "/kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f); w.writerow(rows[0])
+    for r in rows[1:]:
+        if r[0].startswith("(anonymous namespace)::k_"): w.writerow(r)
+PY
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
+  N=$(echo $C | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o pmc_$N -- python bench.py --steps 2 --warmup 1 --cpu-samples 0 > $OUT/pmc_$N.log 2>&1
+  python tools/pmc_summary.py $OUT/pmc_${N}_counter_collection.csv > $OUT/pmc_$N.csv
+  rm -f $OUT/pmc_${N}_counter_collection.csv $OUT/pmc_${N}_kernel_trace.csv
+done
+rm -f $OUT/ks_kernel_trace.csv $OUT/ks_domain_stats.csv $OUT/*agent_info.csv
+ls -la $OUT
