@@ -22,6 +22,11 @@ class EdRefsetRow(C.Structure):
                 ("phi", C.c_double), ("ratio_sd", C.c_double), ("mean_p", C.c_double), ("median_depth", C.c_double)]
 
 
+class EdCallInfo(C.Structure):
+    _fields_ = [("BF_raw", C.c_double), ("BF", C.c_double), ("reads_expected", C.c_int64), ("reads_observed", C.c_int64),
+                ("reads_ratio", C.c_double)]
+
+
 class EdCall(C.Structure):
     _fields_ = [("sample", C.c_int32), ("chrom", C.c_int32), ("start_exon", C.c_int32), ("end_exon", C.c_int32),
                 ("type", C.c_int32), ("nexons", C.c_int32)]
@@ -51,6 +56,7 @@ SYMBOLS = [
     ("ed_batch_n_calls", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_batch_n_gsl_errors", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_batch_copy_calls", C.c_int, [_vp, _vp, _i64]),
+    ("ed_batch_copy_call_info", C.c_int, [_vp, _vp, _i64]),
     ("ed_batch_copy_path", C.c_int, [_vp, _vp]),
     ("ed_batch_copy_loglik", C.c_int, [_vp, _vp]),
     ("ed_batch_enable_timing", C.c_int, [_vp, C.c_int]),

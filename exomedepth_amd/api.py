@@ -20,11 +20,14 @@ import sys
 import numpy as np
 
 from . import _lib
-from ._lib import EdCall, EdError, EdRefsetRow, check, lib
+from ._lib import EdCall, EdCallInfo, EdError, EdRefsetRow, check, lib
 
 CALL_DTYPE = np.dtype([("sample", "<i4"), ("chrom", "<i4"), ("start_exon", "<i4"), ("end_exon", "<i4"),
                        ("type", "<i4"), ("nexons", "<i4")])
 assert CALL_DTYPE.itemsize == C.sizeof(EdCall)
+CALL_INFO_DTYPE = np.dtype([("BF_raw", "<f8"), ("BF", "<f8"), ("reads_expected", "<i8"), ("reads_observed", "<i8"),
+                            ("reads_ratio", "<f8")])
+assert CALL_INFO_DTYPE.itemsize == C.sizeof(EdCallInfo)
 
 
 def _ptr(a):
@@ -249,6 +252,13 @@ class Batch:
         n = self.n_calls()
         out = np.zeros(n, dtype=CALL_DTYPE)
         check(lib().ed_batch_copy_calls(self.handle, _ptr(out), n))
+        return out
+
+    def call_info(self):
+        """BF, reads.expected, reads.observed, reads.ratio of every call (R/class_definition.R:379-405)."""
+        n = self.n_calls()
+        out = np.zeros(n, dtype=CALL_INFO_DTYPE)
+        check(lib().ed_batch_copy_call_info(self.handle, _ptr(out), n))
         return out
 
     def path(self):

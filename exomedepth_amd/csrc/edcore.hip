@@ -623,6 +623,59 @@ k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chr
   if (prev != 0 && k < todo) step(0, m);   // the dummy last observation closes a run that reaches the end
 }
 
+// Decoration of the call table (R/class_definition.R:379-405): per call, BF = sum over its exons of
+// (loglik[type] - loglik[normal]), reads.expected = as.integer(sum(total * expected)), reads.observed =
+// sum(test), reads.ratio.  R's sum() accumulates in long double; here each sum is carried as a
+// double-double (error-free TwoSum), which is at least as accurate, and rounded once.
+__device__ __forceinline__ void dd_add(double& hi, double& lo, double x)
+{
+  const double s = hi + x;
+  const double bb = s - hi;
+  lo += (hi - (s - bb)) + (x - bb);
+  hi = s;
+}
+
+// R's signif(x, 3) for finite non-zero x (src/nmath/fprec.c, the e10 in [-max10e, max10e] branch): scale by a
+// power of ten so that the value has 3 integer digits, round half to even, scale back
+__device__ __forceinline__ double signif3(double x)
+{
+  if (!(x == x) || x == 0.0 || x - x != 0.0) return x;
+  const double ax = fabs(x);
+  int e10 = 2 - (int)floor(log10(ax));
+  double p10 = 1.0;
+  const int n = e10 < 0 ? -e10 : e10;
+  for (int i = 0; i < n; ++i) p10 *= 10.0;
+  double r = (e10 >= 0) ? rint(ax * p10) / p10 : rint(ax / p10) * p10;
+  return x < 0 ? -r : r;
+}
+
+__global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, const double* __restrict__ loglik,
+                            const int32_t* __restrict__ test, const int32_t* __restrict__ ref,
+                            const double* __restrict__ expected, int64_t S, ed_call_info* __restrict__ out)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ncalls) return;
+  const ed_call c = calls[r];
+  const int64_t s = c.sample;
+  const int col = (c.type == 1) ? 0 : 2;   // likelihood columns: deletion, normal, duplication
+  const double p = expected[s];
+  double bh = 0, bl = 0, eh = 0, el = 0;
+  int64_t obs = 0;
+  for (int64_t e = c.start_exon; e <= c.end_exon; ++e) {
+    dd_add(bh, bl, loglik[(e * 3 + col) * S + s] - loglik[(e * 3 + 1) * S + s]);
+    const int32_t t = test[e * S + s];
+    dd_add(eh, el, (double)(t + ref[e * S + s]) * p);
+    obs += t;
+  }
+  ed_call_info o;
+  o.BF_raw = 0.43429448190325182765 * (bh + bl);   // log10(exp(1)) * sum
+  o.BF = signif3(o.BF_raw);
+  o.reads_expected = (int64_t)(eh + el);             // as.integer(): truncation
+  o.reads_observed = obs;
+  o.reads_ratio = signif3((double)obs / (double)o.reads_expected);
+  out[r] = o;
+}
+
 // Single chain with caller-supplied probabilities: the reference's C_hmm signature.
 //   proba nobs x 3 column-major (HMM order), lt [(nobs-1)][9], path_out double[nobs]
 //   calls_out column-major cap x 4, ncalls_out
@@ -934,6 +987,9 @@ struct ed_batch {
   struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
   int64_t calls_cap = 0;
   hipStream_t stream = nullptr;
+  const int32_t* last_test = nullptr;   // inputs of the last ed_batch_run (for ed_batch_copy_call_info)
+  const int32_t* last_ref = nullptr;
+  const double* last_expected = nullptr;
   bool ran = false;
   bool timing = false;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1331,6 +1387,7 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
   const int64_t E = p->E, S = b->S;
   const int32_t C = p->C;
   b->stream = st;
+  b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 8, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
   hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
@@ -1493,6 +1550,25 @@ ED_EXPORT int ed_batch_copy_calls(ed_batch* b, ed_call* host_calls, int64_t cap)
     if (!host_calls) return ed_fail(ED_ERR_INVALID, "NULL output");
     HIP_TRY(hipMemcpy(host_calls, b->d_calls, (size_t)k * sizeof(ed_call), hipMemcpyDeviceToHost));
   }
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int64_t cap)
+{
+  int64_t n = 0;
+  if (int rc = ed_batch_n_calls(b, &n)) return rc;
+  if (n > b->calls_cap)
+    return ed_fail(ED_ERR_STATE, "call table overflow: %lld calls, capacity %lld", (long long)n, (long long)b->calls_cap);
+  const int64_t k = std::min(n, cap);
+  if (k <= 0) return ED_OK;
+  if (!host_info) return ed_fail(ED_ERR_INVALID, "NULL output");
+  DevBuf dinfo;
+  HIP_TRY(dinfo.alloc((size_t)k * sizeof(ed_call_info)));
+  hipLaunchKernelGGL(k_call_info, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, b->stream, b->d_calls, k, b->d_loglik,
+                     b->last_test, b->last_ref, b->last_expected, b->S, dinfo.as<ed_call_info>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(host_info, dinfo.p, (size_t)k * sizeof(ed_call_info), hipMemcpyDeviceToHost));
   return ED_OK;
 }
 

@@ -88,6 +88,15 @@ typedef struct {
   int32_t nexons;     /* the reference's nexons counter, quirks included (src/hmm.cpp:104-126) */
 } ed_call;
 
+/* Decoration of one call, reference R/class_definition.R:379-405 (same order as the call table). */
+typedef struct {
+  double BF_raw;           /* log10(e) * sum(loglik[type] - loglik[normal]) over the call's exons (:390-394, :404) */
+  double BF;               /* signif(BF_raw, 3) (:404) */
+  int64_t reads_expected;  /* as.integer(sum(total * expected)) (:396, :402) */
+  int64_t reads_observed;  /* sum(test) (:397) */
+  double reads_ratio;      /* signif(reads.observed / reads.expected, 3) (:403) */
+} ed_call_info;
+
 typedef struct ed_plan ed_plan;
 typedef struct ed_batch ed_batch;
 
@@ -133,6 +142,9 @@ int ed_batch_n_calls(ed_batch* batch, int64_t* n_calls);
 int ed_batch_n_gsl_errors(ed_batch* batch, int64_t* n_events);
 /* copy results to host buffers (each synchronises) */
 int ed_batch_copy_calls(ed_batch* batch, ed_call* host_calls, int64_t cap);
+/* decoration of the calls (computed on the device from the inputs of the last ed_batch_run, which must still
+ * be valid); host_info[i] belongs to call i of ed_batch_copy_calls */
+int ed_batch_copy_call_info(ed_batch* batch, ed_call_info* host_info, int64_t cap);
 int ed_batch_copy_path(ed_batch* batch, uint8_t* host_path /* [n_exons][n_samples] */);
 int ed_batch_copy_loglik(ed_batch* batch, double* host_loglik /* [n_exons][3][n_samples] */);
 

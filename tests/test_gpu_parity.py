@@ -206,6 +206,7 @@ def _batch_vs_oracle(edlib, oracle, E, S, C, seed, mixture=1.0):
     ll = batch.loglik()
     path = batch.path()
     calls = batch.calls()
+    batch_info = batch.call_info()
     batch.close(); plan.close()
     k = 0
     for s in range(S):
@@ -221,6 +222,17 @@ def _batch_vs_oracle(edlib, oracle, E, S, C, seed, mixture=1.0):
         assert np.array_equal(mine["nexons"], exp_calls[:, 3].astype(np.int64))
         k += len(mine)
     assert k == len(calls)
+    # decoration of the calls (R/class_definition.R:379-405) against a direct numpy evaluation
+    info = batch_info
+    for c, f in list(zip(calls, info))[:200]:
+        s0, a, b = int(c["sample"]), int(c["start_exon"]), int(c["end_exon"])
+        col = 0 if c["type"] == 1 else 2
+        bf = np.log10(np.e) * float(np.sum(ll[a:b + 1, col, s0] - ll[a:b + 1, 1, s0]))
+        assert abs(f["BF_raw"] - bf) <= 1e-12 * max(1.0, abs(bf))
+        assert f["reads_observed"] == int(test[a:b + 1, s0].sum())
+        assert f["reads_expected"] == int(np.sum((test[a:b + 1, s0] + ref[a:b + 1, s0]) * p[s0]))
+        assert f["BF"] == float("%.3g" % bf) or abs(f["BF"] - float("%.3g" % bf)) < 1e-9 * abs(bf)
+        assert abs(f["reads_ratio"] - float("%.3g" % (f["reads_observed"] / f["reads_expected"]))) < 1e-12
     # the call table is ordered by (sample, chromosome, position)
     key = calls["sample"].astype(np.int64) * (E + 1) + calls["start_exon"]
     assert np.all(np.diff(key) >= 0)
