@@ -54,3 +54,26 @@ def test_exomedepth_low_coverage_guard():
     x = ed.ExomeDepth(np.array([0, 1, 2, 9, 9, 9, 9]), np.array([5, 5, 5, 50, 50, 50, 50]))
     assert x.phi.size == 0 and x.likelihood.shape == (0, 3)
     assert x.CallCNVs(["1"] * 7, range(7), range(1, 8), list("abcdefg")).CNV_calls == []
+
+
+def test_count_container_roundtrip(tmp_path):
+    from exomedepth_amd import io
+    rng = np.random.default_rng(8)
+    chrom = ["2"] * 40 + ["X"] * 10 + ["1"] * 50
+    start = np.concatenate([np.sort(rng.integers(1, 10**6, 40)), np.sort(rng.integers(1, 10**6, 10)), np.sort(rng.integers(1, 10**6, 50))[::-1]])
+    end = start + 100
+    counts = rng.integers(0, 500, (100, 7))
+    names = ["e%d" % i for i in range(100)]
+    path = str(tmp_path / "cohort.edc")
+    order = io.write_counts(path, chrom, start, end, counts, sample_names=list("ABCDEFG"), exon_names=names)
+    d = io.read_counts(path)
+    assert d["chrom_names"] == ["1", "2", "X"] and d["chrom_off"].tolist() == [0, 50, 90, 100]
+    assert np.array_equal(d["counts"], counts[order]) and d["counts"].dtype == np.int32
+    assert np.array_equal(d["start"], start[order]) and d["sample_names"] == list("ABCDEFG")
+    assert d["exon_names"] == [names[i] for i in order]
+    assert np.all(np.diff(d["start"][:50]) >= 0)            # chromosome 1 was given in descending order
+    assert d["counts"].offset % 4096 == 0                    # page-aligned block, mappable straight into a Batch
+    assert np.array_equal(io.read_counts(path, mmap=False)["counts"], d["counts"])
+    import pytest
+    with pytest.raises(ValueError):
+        io.write_counts(path, chrom, start, end, counts + 0.5)
