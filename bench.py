@@ -92,11 +92,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ED_BENCH_BACKEND=gloo + ED_BENCH_SHARE_GPU=1 let the N>1 code path be exercised on a 1-GPU box (functional
+    # check only: every rank then uses GPU 0 and the call-table gather goes through host memory)
+    backend = os.environ.get("ED_BENCH_BACKEND", "nccl")
+    if os.environ.get("ED_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    cdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")   # device of the collectives
     if args.gpus != world:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
@@ -134,7 +143,7 @@ def main():
         """final gather of the compact call tables (the path's only collective)"""
         calls = batch.calls()
         if world > 1:
-            t = eddist.calls_to_tensor(calls, dev)
+            t = eddist.calls_to_tensor(calls, cdev)
             g = eddist.gather_call_tables(t, rank * S)
             return int(g.shape[0]) if g is not None else 0
         return len(calls)
@@ -158,7 +167,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -816,11 +816,35 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
   const int64_t e1 = min(e0 + kFitChunk / kFitSub, E);
   edfit::Acc acc = {0, 0, 0, 0, 0};
   double cnt = 0;
-  for (int64_t e = e0; e < e1; e += stride) {
-    const int y = test[e * trs + s * tcs];   // (trs, tcs) = (S, 1): one column per sample; (1, 0): one shared column
-    const int n = y + ref[e * S + s];
-    if (n > 0) cnt += 1.0;
-    edfit::accumulate_cell(acc, a, b, th, y, n);
+  // (trs, tcs) = (S, 1): one test column per sample; (1, 0): one shared test column.
+  // The counts of the next kPre cells are requested before the current ones are consumed: ~150 VALU
+  // instructions per cell do not cover an HBM round trip on their own.
+  constexpr int kPre = 4;
+  int yb[kPre], rb[kPre];
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    const int64_t e = e0 + (int64_t)k * stride;
+    yb[k] = (e < e1) ? test[e * trs + s * tcs] : 0;
+    rb[k] = (e < e1) ? ref[e * S + s] : 0;
+  }
+  for (int64_t e = e0; e < e1; e += (int64_t)kPre * stride) {
+    int yc[kPre], rc[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) { yc[k] = yb[k]; rc[k] = rb[k]; }
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int64_t en = e + (int64_t)(kPre + k) * stride;
+      yb[k] = (en < e1) ? test[en * trs + s * tcs] : 0;
+      rb[k] = (en < e1) ? ref[en * S + s] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      if (e + (int64_t)k * stride < e1) {
+        const int y = yc[k], n = yc[k] + rc[k];
+        if (n > 0) cnt += 1.0;
+        edfit::accumulate_cell(acc, a, b, th, y, n);
+      }
+    }
   }
   double* o = partial + (chunk * kFitQ) * S + s;
   o[0] = acc.ga; o[S] = acc.gb; o[2 * S] = acc.haa; o[3 * S] = acc.hab; o[4 * S] = acc.hbb; o[5 * S] = cnt;
