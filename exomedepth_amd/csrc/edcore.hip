@@ -343,17 +343,24 @@ __device__ __forceinline__ int quad_bcast_i(int x)
   return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, true);
 }
 
-// one forward step of the lane's state; returns the 2-bit back-pointer
+// One forward step of the lane's state; returns the 2-bit back-pointer.
+// The reference scans k = 0,1,2 keeping the first strict maximum, starting from -inf (src/hmm.cpp:78-85), and
+// forces the pointer to 0 when the emission is -inf (:87).  That is: v' = the largest non-NaN candidate or
+// -inf, pointer = the first k attaining it, 0 if nothing exceeds -inf.  IEEE maxNum (v_max_f64: the non-NaN
+// operand wins) seeded with -inf computes exactly that value in 3 dependent instructions instead of 3 x
+// (compare, select, select); the pointer falls out of two equality tests off the critical path.  Candidates
+// are < 0 here (emissions <= 0, log-transitions < 0), so +0/-0 ties cannot arise.  e = -inf makes every
+// candidate -inf or NaN, hence best = -inf and the pointer 0 without a separate test.
 __device__ __forceinline__ unsigned vit_step_q(double& v, double e, double t0, double t1, double t2)
 {
+  const double NI = -HUGE_VAL;
   const double v0 = quad_bcast<0>(v), v1 = quad_bcast<1>(v), v2 = quad_bcast<2>(v);
-  double best = -HUGE_VAL;
-  unsigned fw = 0;
-  double cand;
-  cand = (e + v0) + t0; if (cand > best) { best = cand; fw = 0; }
-  cand = (e + v1) + t1; if (cand > best) { best = cand; fw = 1; }
-  cand = (e + v2) + t2; if (cand > best) { best = cand; fw = 2; }
-  if (e == -HUGE_VAL) fw = 0;   // src/hmm.cpp:87
+  const double c0 = (e + v0) + t0;
+  const double c1 = (e + v1) + t1;
+  const double c2 = (e + v2) + t2;
+  const double best = __builtin_fmax(__builtin_fmax(__builtin_fmax(NI, c0), c1), c2);
+  unsigned fw = (c0 == best) ? 0u : ((c1 == best) ? 1u : 2u);
+  if (best == NI) fw = 0u;
   v = best;
   return fw;
 }
@@ -426,15 +433,18 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
     }
 #pragma unroll
     for (int h = 0; h < kFwdTile / kVitTile; ++h) {
-      // all 16 log-transition rows of the word first (back-to-back LDS reads, one wait), then the chain
-      double2 lrow[kVitTile];
-#pragma unroll
-      for (int k = 0; k < kVitTile; ++k) lrow[k] = lds_lt[buf][h * kVitTile + k][j];
+      // log-transition rows 8 at a time (back-to-back LDS reads, one wait per 8 steps), then the chain
       uint32_t w = 0;
 #pragma unroll
-      for (int k = 0; k < kVitTile; ++k) {
-        const unsigned fw = vit_step_q(v, ecur[h * kVitTile + k], t0, lrow[k].x, lrow[k].y);
-        w |= fw << (2 * k);
+      for (int g8 = 0; g8 < kVitTile / 8; ++g8) {
+        double2 lrow[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lrow[k] = lds_lt[buf][h * kVitTile + g8 * 8 + k][j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned fw = vit_step_q(v, ecur[h * kVitTile + g8 * 8 + k], t0, lrow[k].x, lrow[k].y);
+          w |= fw << (2 * (g8 * 8 + k));
+        }
       }
       if (live) bpc[(t * (kFwdTile / kVitTile) + h) * wstride] = w;
     }
@@ -474,18 +484,20 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   // count is the number of positions q with tb[q] != tb[q+1], tb[q] != 0.
   int count = 0, after = 0;
   uint32_t pw = 0;   // Viterbi states of the current 16-exon word, 2 bits each
-  auto back = [&](uint32_t ww, int k) {
+  // the three states' pointer words of a 16-step word are broadcast across the quad once; per step the
+  // word of the current state is selected and its 2-bit field extracted
+  auto back = [&](uint32_t w0, uint32_t w1, uint32_t w2, int k) {
     pw |= (uint32_t)st << (2 * k);
     count += (st != after && st != 0) ? 1 : 0;
     after = st;
-    const int f = (int)((ww >> (2 * k)) & 3);
-    const int f0 = quad_bcast_i<0>(f), f1 = quad_bcast_i<1>(f), f2 = quad_bcast_i<2>(f);
-    st = (st == 0) ? f0 : ((st == 1) ? f1 : f2);
+    const uint32_t wsel = (st == 0) ? w0 : ((st == 1) ? w1 : w2);
+    st = (int)((wsel >> (2 * k)) & 3u);
   };
   const int64_t nwfull = m / kVitTile;   // full 16-step words
   if (m > nwfull * kVitTile) {
-    const uint32_t ww = (uint32_t)bpc[nwfull * wstride];
-    for (int64_t i = m - 1; i >= nwfull * kVitTile; --i) back(ww, (int)(i & (kVitTile - 1)));
+    const int ww = (int)bpc[nwfull * wstride];
+    const uint32_t w0 = (uint32_t)quad_bcast_i<0>(ww), w1 = (uint32_t)quad_bcast_i<1>(ww), w2 = (uint32_t)quad_bcast_i<2>(ww);
+    for (int64_t i = m - 1; i >= nwfull * kVitTile; --i) back(w0, w1, w2, (int)(i & (kVitTile - 1)));
     if (live && j == 0) ppc[nwfull * S] = pw;
     pw = 0;
   }
@@ -498,10 +510,11 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
     for (int d = 0; d < kDepth; ++d) {
       const int64_t wi = wb - d;
       if (wi < 0) break;
-      const uint32_t ww = ring[d];
+      const int ww = (int)ring[d];
       if (wi - kDepth >= 0) ring[d] = (uint32_t)bpc[(wi - kDepth) * wstride];
+      const uint32_t w0 = (uint32_t)quad_bcast_i<0>(ww), w1 = (uint32_t)quad_bcast_i<1>(ww), w2 = (uint32_t)quad_bcast_i<2>(ww);
 #pragma unroll
-      for (int k = kVitTile - 1; k >= 0; --k) back(ww, k);
+      for (int k = kVitTile - 1; k >= 0; --k) back(w0, w1, w2, k);
       if (live && j == 0) ppc[wi * S] = pw;
       pw = 0;
     }
