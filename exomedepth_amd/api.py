@@ -215,6 +215,14 @@ class Batch:
     def enable_timing(self, on=True):
         check(lib().ed_batch_enable_timing(self.handle, 1 if on else 0))
 
+    def set_fused(self, fused=True):
+        """fused=True: emissions + Viterbi as one kernel (minimal HBM traffic); default is the two-kernel path."""
+        check(lib().ed_batch_set_fused(self.handle, 1 if fused else 0))
+
+    def keep_loglik(self, keep=True):
+        """Keep (default) or drop the (n_exons, 3, n_samples) likelihood matrix -- 24 bytes per cell of HBM."""
+        check(lib().ed_batch_keep_loglik(self.handle, 1 if keep else 0))
+
     def fit(self, test, ref, phi_out, expected_out, stream=None):
         """Per-sample beta-binomial fit (phi, expected) -- counterpart of aod::betabin at reference
         R/class_definition.R:118.  phi_out/expected_out: device float64[n_samples]."""

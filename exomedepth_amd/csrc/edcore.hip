@@ -523,6 +523,12 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   }   // chromosomes of the job
 }
 
+}  // namespace
+
+#include "edfused.inc"
+
+namespace {
+
 // packed states [words][S] -> path [E][S] (one byte per exon).  thread = (sample, word)
 __global__ void __launch_bounds__(256)
 k_path_expand(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chrom_off,
@@ -662,9 +668,12 @@ __device__ __forceinline__ double signif3(double x)
   return x < 0 ? -r : r;
 }
 
+// loglik may be NULL (matrix not kept): the two emissions each exon of a call needs are then recomputed
+// from the per-sample constants -- the same arithmetic, hence the same bits, as the fused kernel produced.
 __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, const double* __restrict__ loglik,
-                            const int32_t* __restrict__ test, const int32_t* __restrict__ ref,
-                            const double* __restrict__ expected, int64_t S, ed_call_info* __restrict__ out)
+                            const double* __restrict__ consts, const int32_t* __restrict__ test,
+                            const int32_t* __restrict__ ref, const double* __restrict__ expected, int64_t S,
+                            ed_call_info* __restrict__ out)
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ncalls) return;
@@ -675,9 +684,21 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
   double bh = 0, bl = 0, eh = 0, el = 0;
   int64_t obs = 0;
   for (int64_t e = c.start_exon; e <= c.end_exon; ++e) {
-    dd_add(bh, bl, loglik[(e * 3 + col) * S + s] - loglik[(e * 3 + 1) * S + s]);
     const int32_t t = test[e * S + s];
-    dd_add(eh, el, (double)(t + ref[e * S + s]) * p);
+    const int32_t tot = t + ref[e * S + s];
+    double lc, ln;
+    if (loglik) {
+      lc = loglik[(e * 3 + col) * S + s];
+      ln = loglik[(e * 3 + 1) * S + s];
+    } else {
+      int flag = 0;
+      lc = edsf::lnbeta(consts[(col * 3 + 0) * S + s] + (double)t, (consts[(col * 3 + 1) * S + s] + (double)tot) - (double)t, &flag) -
+           consts[(col * 3 + 2) * S + s];
+      ln = edsf::lnbeta(consts[(1 * 3 + 0) * S + s] + (double)t, (consts[(1 * 3 + 1) * S + s] + (double)tot) - (double)t, &flag) -
+           consts[(1 * 3 + 2) * S + s];
+    }
+    dd_add(bh, bl, lc - ln);
+    dd_add(eh, el, (double)tot * p);
     obs += t;
   }
   ed_call_info o;
@@ -1028,6 +1049,8 @@ struct ed_batch {
   const int32_t* last_ref = nullptr;
   const double* last_expected = nullptr;
   bool ran = false;
+  bool fused = false;        // run emissions + Viterbi as ONE kernel (edfused.inc) instead of two overlapped ones
+  bool keep_loglik = true;   // fused mode only: also write the [E][3][S] likelihood matrix (the S4 `likelihood` slot)
   bool timing = false;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_run_times = false, have_fit_time = false;
@@ -1302,7 +1325,6 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   b->calls_cap = std::min<int64_t>(std::max<int64_t>(1 << 20, 512 * S), std::max<int64_t>(E * S / 2, 1));
   bool ok = true;
   auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes ? bytes : 1) != hipSuccess) ok = false; };
-  A((void**)&b->d_loglik, (size_t)E * 3 * S * 8);
   A((void**)&b->d_path, (size_t)E * S);
   A((void**)&b->d_bp, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4 * 4);
   A((void**)&b->d_ppath, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4);
@@ -1431,28 +1453,48 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
                      b->d_consts, b->d_cflags);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int64_t cells = E * S;
-  // Emissions are issued group by group (groups of whole chromosomes, longest chromosomes first); when a
-  // group's emissions are done its Viterbi chains start on the side stream and run underneath the
-  // VALU-bound emissions of the following groups.  Only the last group's (short) chains are exposed.
-  HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));   // empty chromosomes: no calls
-  for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) {
-    const int j0 = b->group_off[g], j1 = b->group_off[g + 1];
-    for (int jb = j0; jb < j1; ++jb) {
-      for (int c : b->jobs[jb]) {
-        const int64_t cb = (int64_t)p->chrom_off[c] * S, ce = (int64_t)p->chrom_off[c + 1] * S;
-        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((ce - cb + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells))),
-                           dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, cb, ce, S, b->d_loglik, b->d_nerr);
-      }
+  if (b->fused) {
+    // One fused launch: every workgroup owns 16 samples x one chromosome (longest chromosomes first) and runs
+    // emissions and Viterbi together (edfused.inc); the likelihood matrix is written only if it is kept.
+    HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));   // empty chromosomes: no calls
+    if (b->keep_loglik && !b->d_loglik) {
+      if (hipMalloc((void**)&b->d_loglik, (size_t)std::max<int64_t>(E, 1) * 3 * S * 8) != hipSuccess)
+        return ed_fail(ED_ERR_NOMEM, "ed_batch_run: cannot allocate the likelihood matrix (%lld bytes)", (long long)(E * 3 * S * 8));
     }
-    HIP_TRY(hipEventRecord(b->job_ev[g], st));
-    HIP_TRY(hipStreamWaitEvent(b->side, b->job_ev[g], 0));
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
-                       b->side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
-                       b->d_ppath, b->d_counts, b->d_job_off, b->d_job_chrom, j0);
+    if (cells > 0 && b->n_jobs > 0)
+      hipLaunchKernelGGL(k_emit_viterbi, dim3((unsigned)((S + kFuS - 1) / kFuS), (unsigned)b->n_jobs), dim3(kFuBlock), 0, st,
+                         d_test, d_ref, b->d_consts, b->d_cflags, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C,
+                         b->keep_loglik ? b->d_loglik : (double*)nullptr, b->d_bp, b->d_ppath, b->d_counts, b->d_job_off,
+                         b->d_job_chrom, b->d_nerr);
+    if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
+  } else {
+    if (!b->d_loglik) {
+      if (hipMalloc((void**)&b->d_loglik, (size_t)std::max<int64_t>(E, 1) * 3 * S * 8) != hipSuccess)
+        return ed_fail(ED_ERR_NOMEM, "ed_batch_run: cannot allocate the likelihood matrix");
+    }
+    // Emissions are issued group by group (groups of whole chromosomes, longest chromosomes first); when a
+    // group's emissions are done its Viterbi chains start on the side stream and run underneath the
+    // VALU-bound emissions of the following groups.  Only the last group's (short) chains are exposed.
+    HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));   // empty chromosomes: no calls
+    for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) {
+      const int j0 = b->group_off[g], j1 = b->group_off[g + 1];
+      for (int jb = j0; jb < j1; ++jb) {
+        for (int c : b->jobs[jb]) {
+          const int64_t cb = (int64_t)p->chrom_off[c] * S, ce = (int64_t)p->chrom_off[c + 1] * S;
+          hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((ce - cb + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells))),
+                             dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, cb, ce, S, b->d_loglik, b->d_nerr);
+        }
+      }
+      HIP_TRY(hipEventRecord(b->job_ev[g], st));
+      HIP_TRY(hipStreamWaitEvent(b->side, b->job_ev[g], 0));
+      hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
+                         b->side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
+                         b->d_ppath, b->d_counts, b->d_job_off, b->d_job_chrom, j0);
+    }
+    if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));   // all emissions issued and done on the main stream
+    HIP_TRY(hipEventRecord(b->join_ev, b->side));
+    HIP_TRY(hipStreamWaitEvent(st, b->join_ev, 0));
   }
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));   // all emissions issued and done on the main stream
-  HIP_TRY(hipEventRecord(b->join_ev, b->side));
-  HIP_TRY(hipStreamWaitEvent(st, b->join_ev, 0));
   if (C > 0 && cells > 0 && p->max_words > 0)
     hipLaunchKernelGGL(k_path_expand, dim3((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)C), dim3(256),
                        0, st, b->d_ppath, p->d_chrom_off, p->d_tile_off, S, b->d_path);
@@ -1546,7 +1588,22 @@ ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_
   return ED_OK;
 }
 
-ED_EXPORT const double* ed_batch_loglik(const ed_batch* b) { return b ? b->d_loglik : nullptr; }
+ED_EXPORT const double* ed_batch_loglik(const ed_batch* b) { return (b && (b->keep_loglik || !b->fused)) ? b->d_loglik : nullptr; }
+
+ED_EXPORT int ed_batch_set_fused(ed_batch* b, int fused)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  b->fused = fused != 0;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_keep_loglik(ed_batch* b, int keep)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  b->keep_loglik = keep != 0;
+  if (!b->keep_loglik && b->fused && b->d_loglik) { HIP_TRY(hipFree(b->d_loglik)); b->d_loglik = nullptr; }
+  return ED_OK;
+}
 ED_EXPORT const uint8_t* ed_batch_path(const ed_batch* b) { return b ? b->d_path : nullptr; }
 ED_EXPORT const ed_call* ed_batch_calls(const ed_batch* b) { return b ? b->d_calls : nullptr; }
 
@@ -1601,8 +1658,8 @@ ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int6
   if (!host_info) return ed_fail(ED_ERR_INVALID, "NULL output");
   DevBuf dinfo;
   HIP_TRY(dinfo.alloc((size_t)k * sizeof(ed_call_info)));
-  hipLaunchKernelGGL(k_call_info, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, b->stream, b->d_calls, k, b->d_loglik,
-                     b->last_test, b->last_ref, b->last_expected, b->S, dinfo.as<ed_call_info>());
+  hipLaunchKernelGGL(k_call_info, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, b->stream, b->d_calls, k,
+                     (b->keep_loglik || !b->fused) ? b->d_loglik : (double*)nullptr, b->d_consts, b->last_test, b->last_ref, b->last_expected, b->S, dinfo.as<ed_call_info>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipMemcpy(host_info, dinfo.p, (size_t)k * sizeof(ed_call_info), hipMemcpyDeviceToHost));
@@ -1621,6 +1678,8 @@ ED_EXPORT int ed_batch_copy_loglik(ed_batch* b, double* host_loglik)
 {
   if (int rc = batch_ready(b)) return rc;
   if (!host_loglik) return ed_fail(ED_ERR_INVALID, "NULL output");
+  if ((b->fused && !b->keep_loglik) || !b->d_loglik)
+    return ed_fail(ED_ERR_STATE, "the likelihood matrix is not kept (ed_batch_keep_loglik)");
   HIP_TRY(hipMemcpy(host_loglik, b->d_loglik, (size_t)b->plan->E * 3 * b->S * 8, hipMemcpyDeviceToHost));
   return ED_OK;
 }

@@ -133,6 +133,17 @@ int ed_batch_fit(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, d
 int ed_batch_run(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
                  const double* d_expected, double mixture, void* stream);
 
+/* Execution mode of ed_batch_run.
+ *   fused = 0 (default)  two kernels: emissions into the [n_exons][3][n_samples] likelihood matrix, then Viterbi,
+ *                        overlapped by chromosome groups on two streams -- the fastest path today;
+ *   fused = 1            ONE kernel: producer waves hand each tile of emissions to a Viterbi wave through LDS
+ *                        (csrc/edfused.inc).  HBM traffic drops from ~32 to ~10 bytes per cell and the likelihood
+ *                        matrix becomes an optional by-product (ed_batch_keep_loglik).  Same results bit for bit.
+ * ed_batch_keep_loglik(batch, 0) (fused mode only): do not materialise the matrix -- ed_batch_loglik() returns NULL,
+ * ed_batch_copy_loglik() fails with ED_ERR_STATE, 3*8*n_exons*n_samples bytes of HBM are not allocated. */
+int ed_batch_set_fused(ed_batch* batch, int fused);
+int ed_batch_keep_loglik(ed_batch* batch, int keep);
+
 /* device-resident results of the last ed_batch_run */
 const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples] */
 const uint8_t* ed_batch_path(const ed_batch* batch);   /* [n_exons][n_samples]    */

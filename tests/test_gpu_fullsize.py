@@ -99,6 +99,17 @@ def test_call_table_is_the_run_length_encoding_of_the_path(full):
     assert 0.0005 < nz.mean() < 0.02
 
 
+def test_fused_mode_gives_identical_results_at_full_size(full):
+    """emissions + Viterbi as ONE kernel, likelihood matrix not materialised: same path, same calls."""
+    b = full["edlib"].Batch(full["plan"], S)
+    b.set_fused(True); b.keep_loglik(False)
+    b.run(full["test"], full["ref"], full["phi"], full["p"])
+    assert np.array_equal(b.path(), full["path"])
+    assert np.array_equal(b.calls(), full["calls"])
+    assert np.array_equal(b.call_info(), full["batch"].call_info())
+    b.close()
+
+
 def test_subset_of_samples_gives_the_same_columns(full):
     torch = full["torch"]
     cols = slice(192, 256)

@@ -196,14 +196,22 @@ def test_viterbi_random_chains_bit_exact(edlib, oracle):
         assert np.array_equal(gc, c)
 
 
-def _batch_vs_oracle(edlib, oracle, E, S, C, seed, mixture=1.0):
+def _batch_vs_oracle(edlib, oracle, E, S, C, seed, mixture=1.0, fused=False, keep=True):
     from exomedepth_amd import synth
     chrom_off, start, end = synth.exon_design(E, C, seed)
     test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=3, mean_depth=60.0)
     plan = edlib.Plan(chrom_off, start, end)
     batch = edlib.Batch(plan, S)
+    batch.set_fused(fused)
+    batch.keep_loglik(keep)
     batch.run(test, ref, phi, p, mixture=mixture)
-    ll = batch.loglik()
+    if fused and not keep:
+        with pytest.raises(edlib.EdError):
+            batch.loglik()
+        ll = np.stack([oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], mixture, oracle.PORTABLE)[0]
+                       for s in range(S)], axis=2)   # call decoration is checked against the checker instead
+    else:
+        ll = batch.loglik()
     path = batch.path()
     calls = batch.calls()
     batch_info = batch.call_info()
@@ -239,14 +247,17 @@ def _batch_vs_oracle(edlib, oracle, E, S, C, seed, mixture=1.0):
     return len(calls)
 
 
-def test_batch_pipeline_parity_small(edlib, oracle):
-    n = _batch_vs_oracle(edlib, oracle, E=3000, S=70, C=5, seed=5)   # ragged: S not a multiple of 64
+@pytest.mark.parametrize("fused,keep", [(False, True), (True, True), (True, False)])
+def test_batch_pipeline_parity_small(edlib, oracle, fused, keep):
+    n = _batch_vs_oracle(edlib, oracle, E=3000, S=70, C=5, seed=5, fused=fused, keep=keep)   # ragged: S not a multiple of 16/64
     assert n > 0
 
 
-def test_batch_pipeline_parity_tumor_mixture_and_tiny(edlib, oracle):
-    _batch_vs_oracle(edlib, oracle, E=400, S=3, C=24, seed=6, mixture=0.6)
-    _batch_vs_oracle(edlib, oracle, E=64, S=1, C=1, seed=7)
+@pytest.mark.parametrize("fused", [False, True])
+def test_batch_pipeline_parity_tumor_mixture_and_tiny(edlib, oracle, fused):
+    _batch_vs_oracle(edlib, oracle, E=400, S=3, C=24, seed=6, mixture=0.6, fused=fused)
+    _batch_vs_oracle(edlib, oracle, E=64, S=1, C=1, seed=7, fused=fused, keep=not fused)
+    _batch_vs_oracle(edlib, oracle, E=33, S=17, C=2, seed=8, fused=fused)   # a one-exon last tile, 2 ragged sample tiles
 
 
 def test_batch_empty_chromosomes(edlib, oracle):
