@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--samples", type=int, default=1024, help="samples per GPU")
     ap.add_argument("--chroms", type=int, default=24)
     ap.add_argument("--fit", type=int, default=1, help="1 (default): the step includes the per-sample dispersion fit (configs[2]); 0: phi given (configs[1] style)")
+    ap.add_argument("--fused", type=int, default=0, help="1: emissions + Viterbi as one kernel (csrc/edfused.inc)")
+    ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -128,6 +130,8 @@ def main():
     plan = ed.Plan(chrom_off, start, end, 1e-4, 50000.0, device=local_rank)
     batch = ed.Batch(plan, S)
     batch.enable_timing(True)
+    batch.set_fused(bool(args.fused))
+    batch.keep_loglik(bool(args.keep_loglik))
     stream = torch.cuda.current_stream().cuda_stream
     phi_fit = torch.empty(S, dtype=torch.float64, device=dev)
     p_fit = torch.empty(S, dtype=torch.float64, device=dev)
@@ -188,7 +192,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
-                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit),
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": "k_emit_batch", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

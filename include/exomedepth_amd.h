@@ -105,8 +105,9 @@ typedef struct ed_batch ed_batch;
  *   exons must already be ordered by (chromosome, position) as :323-336 orders them;
  *   chrom_off[n_chrom+1] delimits the chromosomes (chains, :354); start/end are the exon coordinates.
  * Creating the plan builds, on the host with libm exactly as src/hmm.cpp:62-79 does, the
- * distance-dependent log-transition table of every exon gap (9 doubles per gap, shared by all
- * samples) and uploads it. */
+ * distance-dependent log-transition table of every exon gap (8 doubles per gap, shared by all
+ * samples: for each of the 4 quad lanes the two distance-dependent entries of its into-state;
+ * the from-normal entry does not depend on the distance) and uploads it. */
 int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_t n_chrom, const int32_t* chrom_off,
                    const int32_t* start, const int32_t* end, double transition_probability,
                    double expected_cnv_length);
