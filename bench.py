@@ -27,8 +27,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # FP64 vector peak (no MFMA applies to this path)
 ALGO_BYTES_PER_CELL = 9        # read test 4 B + read reference 4 B + write state 1 B
 
 
-def pmc_traffic():
-    """HBM bytes per k_emit_batch launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+def pmc_traffic(kernel, n_launch):
+    """HBM bytes per launch of `kernel` (n_launch launches per step) from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
     written by tools/profile_to_json.py): FETCH_SIZE x2 (gfx950 tallies the 128-byte requests of a coalesced
     stream at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> bytes.  None if no profile is committed."""
     import glob
@@ -36,7 +36,11 @@ def pmc_traffic():
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    return d["k_emit_batch"]["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    if kernel not in d:
+        return None, None
+    k = d[kernel]   # per-step total of the profiled run, re-divided by this run's launches per step
+    per_step = k["hbm_bytes_per_launch"] * k["launches_profiled"] / k.get("steps_profiled", 3)
+    return per_step / n_launch, os.path.basename(files[-1])
 
 
 def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit):
@@ -182,8 +186,8 @@ def main():
     if rank == 0:
         t_emit = stage_ms["emissions"] * 1e-3
         achieved = ALGO_BYTES_PER_CELL * E * S / t_emit / 1e9 if t_emit > 0 else 0.0
-        traffic, traffic_src = pmc_traffic()
-        n_launch = max(1, plan.n_chrom)   # the emissions are issued one launch per chromosome
+        n_launch = max(1, batch.n_emit_launches)   # one emission launch per overlap group of chromosomes
+        traffic, traffic_src = pmc_traffic("k_emit_viterbi" if args.fused else "k_emit_batch", n_launch)
         out = {
             "metric": "exons*samples/s through betabinom emissions + Viterbi" + (" + dispersion fit" if args.fit else ""),
             "value": value, "unit": "exons*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,7 +198,7 @@ def main():
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
                        "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered over RCCL" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_emit_batch", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_emit_viterbi" if args.fused else "k_emit_batch", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_cell": ALGO_BYTES_PER_CELL, "launches_per_step": n_launch,
                          "kernel_ms": stage_ms["emissions"] / n_launch, "kernel_ms_per_step": stage_ms["emissions"],

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("ed_batch_run", C.c_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp]),
     ("ed_batch_set_fused", C.c_int, [_vp, C.c_int]),
     ("ed_batch_keep_loglik", C.c_int, [_vp, C.c_int]),
+    ("ed_batch_n_emit_launches", C.c_int, [_vp]),
     ("ed_batch_loglik", _vp, [_vp]),
     ("ed_batch_path", _vp, [_vp]),
     ("ed_batch_calls", _vp, [_vp]),

@@ -223,6 +223,11 @@ class Batch:
         """Keep (default) or drop the (n_exons, 3, n_samples) likelihood matrix -- 24 bytes per cell of HBM."""
         check(lib().ed_batch_keep_loglik(self.handle, 1 if keep else 0))
 
+    @property
+    def n_emit_launches(self):
+        """emission-kernel launches per run (overlap groups; 1 in fused mode)"""
+        return int(lib().ed_batch_n_emit_launches(self.handle))
+
     def fit(self, test, ref, phi_out, expected_out, stream=None):
         """Per-sample beta-binomial fit (phi, expected) -- counterpart of aod::betabin at reference
         R/class_definition.R:118.  phi_out/expected_out: device float64[n_samples]."""

@@ -20,6 +20,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/exomedepth_amd.h"
@@ -119,10 +120,11 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
 // one exon (coalesced) and writes three coalesced rows of the [E][3][S] likelihood matrix.
 constexpr int kEmitCells = 2;                                // cells per thread
 constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per workgroup
+constexpr int64_t kEmitHeadBlocks = 2048;                    // workgroups of a group's short leading launch (ed_batch_run)
 
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
-             const int* __restrict__ cflags, int64_t cell_begin, int64_t cell_end, int64_t S,
+             const int* __restrict__ cflags, const int64_t* __restrict__ seg, int nseg, int64_t blk_base, int64_t S,
              double* __restrict__ loglik, unsigned long long* __restrict__ nerr)
 {
   __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
@@ -133,8 +135,14 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   const int lane = tid & 63;
   if (tid == 0) { n_front = 0; n_back = 0; }
   __syncthreads();
-  const int64_t ncell = cell_end;   // this launch covers cells [cell_begin, cell_end): whole chromosomes
-  const int64_t cell0 = cell_begin + (int64_t)blockIdx.x * (kEmitBlock * kEmitCells) + tid;
+  // The batch's cells are cut into nseg segments of whole chromosomes (job order); seg[3*i .. 3*i+2] = (first
+  // workgroup, first cell, end cell) of segment i.  This launch covers workgroups blk_base .. blk_base+gridDim.x-1
+  // of that numbering; a short uniform search finds the workgroup's segment.
+  const int64_t blk = (int64_t)blockIdx.x + blk_base;
+  int si = 0;
+  while (si + 1 < nseg && seg[3 * (si + 1)] <= blk) ++si;
+  const int64_t ncell = seg[3 * si + 2];
+  const int64_t cell0 = seg[3 * si + 1] + (blk - seg[3 * si]) * (kEmitBlock * kEmitCells) + tid;
   int slot[kEmitCells * 3];
   int nflag = 0;
   // ---- phase 1: classify and scatter the tasks ----
@@ -327,7 +335,7 @@ __device__ __forceinline__ int summarise_chain(int64_t last, TB tb, EMIT emit)
 // (0,-inf,-inf) (src/hmm.cpp:48-52; the first dummy row is never read) and ends with one extra step
 // whose emissions are (-100, 0, -100).
 constexpr int kVitTile = 16;      // steps per back-pointer / packed-state word
-constexpr int kFwdTile = 16;      // forward prefetch tile (steps); a multiple of kVitTile
+
 constexpr int kVitChains = 16;    // chains per wave
 
 template <int K>
@@ -365,7 +373,13 @@ __device__ __forceinline__ unsigned vit_step_q(double& v, double e, double t0, d
   return fw;
 }
 
-__global__ void __launch_bounds__(kWave)
+// Register budget: a Viterbi wave shares its SIMD with emission waves (96 registers each; ed_batch_run overlaps
+// the two kernels), so its own allocation decides how many of them stay resident beside it: 154 registers
+// (no scratch) leave room for three.  Measured on MI355X: a 128-register build (four) is no faster.
+#ifndef ED_VIT_OCC
+#define ED_VIT_OCC 3
+#endif
+__global__ void __launch_bounds__(kWave, ED_VIT_OCC)
 k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, double c0, double c1,
           const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off, int64_t S, int32_t C,
           uint32_t* __restrict__ bpq, uint32_t* __restrict__ ppath, int32_t* __restrict__ counts,
@@ -376,7 +390,7 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   const int64_t s_raw = (int64_t)blockIdx.x * kVitChains + (lane >> 2);
   const bool live = s_raw < S;
   const int64_t s = live ? s_raw : S - 1;   // idle quads shadow the last sample (loads stay in bounds, no stores)
-  __shared__ double2 lds_lt[2][kFwdTile][4];
+  __shared__ double2 lds_lt[2][kVitTile][4];
   // A workgroup runs a JOB: one or more whole chromosomes, one after the other.  The host packs the
   // chromosomes into jobs of about the longest chromosome's length so that, when the batch has fewer
   // waves than the chip has SIMDs, every wave has a SIMD to itself and the makespan is one long chain.
@@ -392,7 +406,6 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   __syncthreads();   // the previous chromosome's readers are done with lds_lt
   const int col = (j == 1) ? 0 : ((j == 2) ? 2 : 1);
   const int64_t estride = 3 * S;                                  // doubles between consecutive exons
-  const double* __restrict__ em = loglik + (lo * 3 + col) * S + s; // step i: em[i * estride]
   const double2* __restrict__ ltp = reinterpret_cast<const double2*>(lt4) + (lo + c) * 4 + j;  // step i: ltp[i * 4]
   uint32_t* __restrict__ bpc = bpq + (word_off[c] * S + s) * 4 + j;                            // word w: bpc[w * S * 4]
   const int64_t wstride = S * 4;
@@ -401,72 +414,69 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   double v = (j == 0 || j == 3) ? 0.0 : -HUGE_VAL;
 
   // ---- forward pass ----
-  // Tiles of kFwdTile steps.  Emissions of tile t+1 are in flight (registers) while tile t is computed;
-  // the log-transitions of tile t+1 are fetched by the wave as one 16-byte load per lane per 16 steps,
-  // parked in LDS, and read back per step (every quad reads the same 64 bytes, its lane its own 16).
-  // Full tiles run without per-step guards (the table carries padding, so its prefetch may run past the
-  // chromosome's last gap); the remaining < kFwdTile steps take a plain loop.
-  const int64_t nfull = m / kFwdTile;
-  double ecur[kFwdTile], enxt[kFwdTile];
-  double2 stage[kFwdTile / 16];
-  const double2* __restrict__ ltw = reinterpret_cast<const double2*>(lt4) + (lo + c) * 4;   // wave-level view
-  if (nfull > 0) {
+  // Emissions live in a register ring of kRing steps: step i's value sits in er[i % kRing] and, as soon as
+  // it is consumed, the slot is re-loaded with step i + kRing (clamped to the chromosome's last exon, a
+  // scalar min), so loads are always kRing steps ahead of their use and nothing is copied.  Addresses are a
+  // wave-uniform base (scalar registers) plus one 32-bit lane offset.  The log-transition rows of tile t+1
+  // are fetched by the wave as one 16-byte load per lane at the start of tile t, parked in LDS at the end of
+  // tile t and read back per step (every quad reads the same 64 bytes, its lane its own 16); the table
+  // carries padding, so this prefetch may run past the chromosome's last gap.  The loop is unrolled over two
+  // tiles so that ring slots and LDS buffers are compile-time; the last (possibly partial) tiles take the
+  // guarded instance, whose guards are scalar branches.
+  constexpr int kRing = 2 * kVitTile;
+  const double* __restrict__ emb = loglik + lo * 3 * S;                                    // wave-uniform
+  const uint32_t eoff = (uint32_t)(col * S + s);                                           // lane part
+  uint32_t* __restrict__ bpb = bpq + word_off[c] * S * 4;                                  // wave-uniform
+  const uint32_t boff = (uint32_t)(s * 4 + j);
+  const double2* __restrict__ ltw = reinterpret_cast<const double2*>(lt4) + (lo + c) * 4;  // wave-level view
+  const int m32 = (int)m;   // chromosome lengths are int32 (chrom_off); 32-bit so that the clamp is one s_min_i32
+  auto em_at = [&](int i) { return emb[(int64_t)(i < m32 ? i : m32 - 1) * estride + eoff]; };
+  double er[kRing];
+  double2 stg = ltw[lane];
 #pragma unroll
-    for (int r = 0; r < kFwdTile / 16; ++r) stage[r] = ltw[r * 64 + lane];
+  for (int k = 0; k < kRing; ++k) er[k] = em_at(k);
+  (&lds_lt[0][0][0])[lane] = stg;
+  __syncthreads();
+  auto tile = [&](auto par, auto full, int t, int nsteps) {
+    constexpr int P = decltype(par)::value;
+    constexpr bool kFull = decltype(full)::value;
+    stg = ltw[(t + 1) * 64 + lane];
+    uint32_t w = 0;
 #pragma unroll
-    for (int k = 0; k < kFwdTile; ++k) ecur[k] = em[k * estride];
+    for (int g4 = 0; g4 < kVitTile / 4; ++g4) {
+      double2 lrow[4];
 #pragma unroll
-    for (int r = 0; r < kFwdTile / 16; ++r) (&lds_lt[0][0][0])[r * 64 + lane] = stage[r];
-    __syncthreads();
-  }
-  for (int64_t t = 0; t < nfull; ++t) {
-    const int64_t base = t * kFwdTile;
-    const int buf = (int)(t & 1);
-    const bool more = t + 1 < nfull;
-    if (more) {
-      const double2* __restrict__ lq = ltw + (base + kFwdTile) * 4;
+      for (int k = 0; k < 4; ++k) lrow[k] = lds_lt[P][g4 * 4 + k][j];
 #pragma unroll
-      for (int r = 0; r < kFwdTile / 16; ++r) stage[r] = lq[r * 64 + lane];
-      const double* __restrict__ q = em + (base + kFwdTile) * estride;
-#pragma unroll
-      for (int k = 0; k < kFwdTile; ++k) enxt[k] = q[k * estride];
-    }
-#pragma unroll
-    for (int h = 0; h < kFwdTile / kVitTile; ++h) {
-      // log-transition rows 8 at a time (back-to-back LDS reads, one wait per 8 steps), then the chain
-      uint32_t w = 0;
-#pragma unroll
-      for (int g8 = 0; g8 < kVitTile / 8; ++g8) {
-        double2 lrow[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lrow[k] = lds_lt[buf][h * kVitTile + g8 * 8 + k][j];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const unsigned fw = vit_step_q(v, ecur[h * kVitTile + g8 * 8 + k], t0, lrow[k].x, lrow[k].y);
-          w |= fw << (2 * (g8 * 8 + k));
+      for (int k = 0; k < 4; ++k) {
+        const int kk = g4 * 4 + k;
+        if (kFull || kk < nsteps) {
+          unsigned fw = vit_step_q(v, er[P * kVitTile + kk], t0, lrow[k].x, lrow[k].y);
+          // pin the pointer to a register here: otherwise the compiler defers all 16 pointer computations of the
+          // tile to the store below (keeping 3 doubles per step alive) and turns the shifts into constant tables
+          asm("" : "+v"(fw));
+          w |= fw << (2 * kk);
+          er[P * kVitTile + kk] = em_at(t * kVitTile + kk + kRing);
         }
       }
-      if (live) bpc[(t * (kFwdTile / kVitTile) + h) * wstride] = w;
     }
-    if (more) {
-#pragma unroll
-      for (int r = 0; r < kFwdTile / 16; ++r) (&lds_lt[buf ^ 1][0][0])[r * 64 + lane] = stage[r];
-#pragma unroll
-      for (int k = 0; k < kFwdTile; ++k) ecur[k] = enxt[k];
-    }
+    bpb[(int64_t)t * wstride + boff] = w;   // idle quads shadow sample S-1: same value to the same address
+    (&lds_lt[P ^ 1][0][0])[lane] = stg;
     __syncthreads();
-  }
+  };
   {
-    // the remaining steps (fewer than kFwdTile), one back-pointer word per 16
-    uint32_t w = 0;
-    for (int64_t i = nfull * kFwdTile; i < m; ++i) {
-      const double2 l = ltp[i * 4];
-      const unsigned fw = vit_step_q(v, em[i * estride], t0, l.x, l.y);
-      w |= fw << (2 * (int)(i & (kVitTile - 1)));
-      if ((i & (kVitTile - 1)) == kVitTile - 1 || i == m - 1) {
-        if (live) bpc[(i / kVitTile) * wstride] = w;
-        w = 0;
-      }
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    const int nfull = m32 / kVitTile, ntile = (m32 + kVitTile - 1) / kVitTile;
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+      tile(I0{}, std::true_type{}, t, kVitTile);
+      tile(I1{}, std::true_type{}, t + 1, kVitTile);
+    }
+    for (; t < ntile; ++t) {   // at most two: a last full tile and/or the partial one
+      const int nst = (m32 - t * kVitTile < kVitTile) ? (m32 - t * kVitTile) : kVitTile;
+      if (t & 1) tile(I1{}, std::false_type{}, t, nst);
+      else tile(I0{}, std::false_type{}, t, nst);
     }
   }
   // dummy last observation (R/class_definition.R:364): only state 0's back-pointer is ever used
@@ -1029,6 +1039,8 @@ struct ed_batch {
   uint32_t* d_ppath = nullptr;   // [n_words][S] packed Viterbi states (16 exons x 2 bits)
   int32_t* d_job_off = nullptr;  // [n_jobs + 1]
   int32_t* d_job_chrom = nullptr;  // chromosomes in job order
+  int64_t* d_seg = nullptr;        // emission segments in job order: (first workgroup, first cell, end cell) x n_jobs
+  std::vector<int64_t> seg;        // host copy (+ one closing entry holding the total workgroup count)
   int32_t n_jobs = 0;
   std::vector<std::vector<int>> jobs;   // host copy: chromosomes of each Viterbi job
   std::vector<int32_t> group_off;       // job ranges of the overlap groups
@@ -1401,7 +1413,13 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     for (auto& jb : jobs) { for (int c : jb) jchr.push_back(c); joff.push_back((int32_t)jchr.size()); }
     b->n_jobs = (int32_t)jobs.size();
     b->jobs = jobs;
-    HIP_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    {
+      // the latency-bound Viterbi workgroups must not queue behind the thousands of pending emission
+      // workgroups of the next group: the side stream gets the highest dispatch priority
+      int least = 0, greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_TRY(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, greatest));
+    }
     b->job_ev.resize(b->group_off.size());
     for (auto& e : b->job_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
@@ -1409,6 +1427,17 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     HIP_TRY(hipMalloc((void**)&b->d_job_chrom, std::max<size_t>(jchr.size(), 1) * 4));
     HIP_TRY(hipMemcpy(b->d_job_off, joff.data(), joff.size() * 4, hipMemcpyHostToDevice));
     if (!jchr.empty()) HIP_TRY(hipMemcpy(b->d_job_chrom, jchr.data(), jchr.size() * 4, hipMemcpyHostToDevice));
+    // emission segments: one per job (= chromosome), in job order, so that a whole group is ONE launch
+    int64_t blk = 0;
+    for (auto& jb : jobs) {
+      const int c = jb[0];
+      const int64_t cb = (int64_t)plan->chrom_off[c] * S, ce = (int64_t)plan->chrom_off[c + 1] * S;
+      b->seg.push_back(blk); b->seg.push_back(cb); b->seg.push_back(ce);
+      blk += (ce - cb + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells);
+    }
+    b->seg.push_back(blk); b->seg.push_back(0); b->seg.push_back(0);
+    HIP_TRY(hipMalloc((void**)&b->d_seg, b->seg.size() * 8));
+    HIP_TRY(hipMemcpy(b->d_seg, b->seg.data(), b->seg.size() * 8, hipMemcpyHostToDevice));
   }
   for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
   *batch = b;
@@ -1421,7 +1450,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -1478,13 +1507,17 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
     HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));   // empty chromosomes: no calls
     for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) {
       const int j0 = b->group_off[g], j1 = b->group_off[g + 1];
-      for (int jb = j0; jb < j1; ++jb) {
-        for (int c : b->jobs[jb]) {
-          const int64_t cb = (int64_t)p->chrom_off[c] * S, ce = (int64_t)p->chrom_off[c + 1] * S;
-          hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)((ce - cb + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells))),
-                             dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, cb, ce, S, b->d_loglik, b->d_nerr);
-        }
-      }
+      // One launch per group, except that a group following another starts with a short separate launch: the
+      // previous group's Viterbi workgroups (side stream) are dispatched into the slots freed at that launch
+      // boundary instead of queueing behind this group's thousands of pending workgroups.
+      const int64_t blk0 = b->seg[3 * j0], nblk = b->seg[3 * j1] - blk0;
+      const int64_t head = (g > 0) ? std::min<int64_t>(nblk, kEmitHeadBlocks) : 0;
+      if (head > 0)
+        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
+                           b->d_seg, b->n_jobs, blk0, S, b->d_loglik, b->d_nerr);
+      if (nblk - head > 0)
+        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
+                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, b->d_loglik, b->d_nerr);
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
       HIP_TRY(hipStreamWaitEvent(b->side, b->job_ev[g], 0));
       hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
@@ -1595,6 +1628,19 @@ ED_EXPORT int ed_batch_set_fused(ed_batch* b, int fused)
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->fused = fused != 0;
   return ED_OK;
+}
+
+ED_EXPORT int ed_batch_n_emit_launches(const ed_batch* b)
+{
+  if (!b) return 0;
+  if (b->fused) return 1;
+  int n = 0;
+  for (size_t g = 0; g + 1 < b->group_off.size(); ++g) {
+    const int64_t nblk = b->seg[3 * b->group_off[g + 1]] - b->seg[3 * b->group_off[g]];
+    const int64_t head = (g > 0) ? std::min<int64_t>(nblk, kEmitHeadBlocks) : 0;
+    n += (head > 0) + (nblk - head > 0);
+  }
+  return n;
 }
 
 ED_EXPORT int ed_batch_keep_loglik(ed_batch* b, int keep)

@@ -144,6 +144,9 @@ int ed_batch_run(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, c
  * ed_batch_copy_loglik() fails with ED_ERR_STATE, 3*8*n_exons*n_samples bytes of HBM are not allocated. */
 int ed_batch_set_fused(ed_batch* batch, int fused);
 int ed_batch_keep_loglik(ed_batch* batch, int keep);
+/* Number of emission-kernel launches one ed_batch_run issues (= overlap groups; 1 in fused mode): the
+ * denominator of per-launch figures in bench.py. */
+int ed_batch_n_emit_launches(const ed_batch* batch);
 
 /* device-resident results of the last ed_batch_run */
 const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples] */

@@ -10,7 +10,8 @@ def load(name):
 f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
 out = {}
 for k in f:
-    out[k] = {"FETCH_SIZE_KB_per_launch": f[k][0], "WRITE_SIZE_KB_per_launch": w.get(k, (0, 0))[0], "launches_profiled": f[k][1],
+    out[k] = {"FETCH_SIZE_KB_per_launch": f[k][0], "WRITE_SIZE_KB_per_launch": w.get(k, (0, 0))[0], "launches_profiled": f[k][1], "steps_profiled": 3,   # profile_round.sh: --steps 2 --warmup 1
+             
               "hbm_bytes_per_launch": (2.0 * f[k][0] + w.get(k, (0, 0))[0]) * 1024.0,
               "correction": "FETCH_SIZE x2 (coalesced streams, gfx950); WRITE_SIZE as reported"}
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
