@@ -228,16 +228,17 @@ class Batch:
         """emission-kernel launches per run (overlap groups; 1 in fused mode)"""
         return int(lib().ed_batch_n_emit_launches(self.handle))
 
-    def fit(self, test, ref, phi_out, expected_out, stream=None):
+    def fit(self, test, ref, phi_out, expected_out, stream=None, by=1):
         """Per-sample beta-binomial fit (phi, expected) -- counterpart of aod::betabin at reference
-        R/class_definition.R:118.  phi_out/expected_out: device float64[n_samples]."""
+        R/class_definition.R:118.  phi_out/expected_out: device float64[n_samples].
+        by > 1: fit on exons 0, by, 2*by, ... only (scalar subset.for.speed = n  <=>  by = n_exons // n, :107-113)."""
         keep = []
         pt = _device_pointer(test, np.int32, keep)
         pr = _device_pointer(ref, np.int32, keep)
         pp = _device_pointer(phi_out, np.float64, keep)
         pe = _device_pointer(expected_out, np.float64, keep)
         self._keep = keep
-        check(lib().ed_batch_fit(self.handle, pt, pr, pp, pe, C.c_void_p(stream or 0)))
+        check(lib().ed_batch_fit_subset(self.handle, pt, pr, int(by), pp, pe, C.c_void_p(stream or 0)))
 
     def run(self, test, ref, phi, expected, mixture=1.0, stream=None):
         """Emissions + Viterbi + call table.  Arguments may be torch CUDA tensors (used in place),
@@ -329,7 +330,7 @@ class ExomeDepth:
     phi / expected: if given, the fixed dispersion and expected proportion (the reference gets them
     from aod::betabin, :118, :168); if omitted they are fitted on the GPU (ed_batch_fit)."""
 
-    def __init__(self, test, reference, phi=None, expected=None, prop_tumor=1.0, verbose=False):
+    def __init__(self, test, reference, phi=None, expected=None, prop_tumor=1.0, subset_for_speed=None, verbose=False):
         test = np.asarray(test, dtype=np.float64)
         reference = np.asarray(reference, dtype=np.float64)
         if test.size != reference.size:
@@ -347,7 +348,18 @@ class ExomeDepth:
             return
         n = test.size
         if phi is None or expected is None:
-            phi, expected = fit_betabin(_as_r_integer(test), _as_r_integer(reference))
+            rows = np.arange(n)
+            if subset_for_speed is not None:                           # R/class_definition.R:107-113
+                sub = np.atleast_1d(np.asarray(subset_for_speed))
+                if sub.size == 1 and np.issubdtype(sub.dtype, np.number):
+                    by = int(np.floor(n / float(sub[0])))
+                    if by < 1:
+                        raise ValueError("wrong sign in 'by' argument")   # R's seq() error for by = 0
+                    rows = np.arange(0, n, by)                         # seq(from = 1, to = nrow, by = floor(nrow / n))
+                else:
+                    sub = sub.astype(np.int64)
+                    rows = sub[(sub >= 1) & (sub <= n)] - 1            # keep existing (1-based) rows only
+            phi, expected = fit_betabin(_as_r_integer(test[rows]), _as_r_integer(reference[rows]))
         self.phi = np.full(n, float(phi)) if np.ndim(phi) == 0 else _f64(phi)
         self.expected = np.full(n, float(expected)) if np.ndim(expected) == 0 else _f64(expected)
         self.likelihood = np.array(get_loglike_matrix(self.phi, self.expected, _as_r_integer(reference + test),

@@ -764,8 +764,8 @@ constexpr int kFitQ = 6;            // quantities per partial
 
 // moments for the starting point: sum y, sum n, sum y^2/n, #cells with n > 0
 __global__ void __launch_bounds__(kWave * kFitSub)
-k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t E,
-              int64_t S, int stride, double* __restrict__ partial)
+k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t rrs,
+              int64_t E, int64_t S, int stride, double* __restrict__ partial)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
   const int sub = threadIdx.y;
@@ -776,7 +776,7 @@ k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const 
   double sy = 0, sn = 0, syy = 0, cnt = 0;
   for (int64_t e = e0; e < e1; e += stride) {
     const int y = test[e * trs + s * tcs];   // (trs, tcs) = (S, 1): one column per sample; (1, 0): one shared column
-    const int n = y + ref[e * S + s];
+    const int n = y + ref[e * rrs + s];
     if (n > 0) {
       sy += (double)y; sn += (double)n;
       syy += ((double)y * (double)y) / (double)n;
@@ -844,8 +844,8 @@ k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, doubl
 }
 
 __global__ void __launch_bounds__(kWave * kFitSub)
-k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t E,
-            int64_t S, int stride, const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
+k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t rrs,
+            int64_t E, int64_t S, int stride, const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
             double* __restrict__ partial)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
@@ -869,7 +869,7 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
   for (int k = 0; k < kPre; ++k) {
     const int64_t e = e0 + (int64_t)k * stride;
     yb[k] = (e < e1) ? test[e * trs + s * tcs] : 0;
-    rb[k] = (e < e1) ? ref[e * S + s] : 0;
+    rb[k] = (e < e1) ? ref[e * rrs + s] : 0;
   }
   for (int64_t e = e0; e < e1; e += (int64_t)kPre * stride) {
     int yc[kPre], rc[kPre];
@@ -879,7 +879,7 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
     for (int k = 0; k < kPre; ++k) {
       const int64_t en = e + (int64_t)(kPre + k) * stride;
       yb[k] = (en < e1) ? test[en * trs + s * tcs] : 0;
-      rb[k] = (en < e1) ? ref[en * S + s] : 0;
+      rb[k] = (en < e1) ? ref[en * rrs + s] : 0;
     }
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
@@ -1575,25 +1575,25 @@ static void fitwork_free(FitWork* w)
   if (w) { w->release(); delete w; }
 }
 
-// Fit S columns: column s has test counts test[e*trs + s*tcs] and reference counts ref[e*S + s], e < E.
-static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t E,
-                       int64_t S, double* d_phi, double* d_expected, hipStream_t st)
+// Fit S columns: column s has test counts test[e*trs + s*tcs] and reference counts ref[e*rrs + s], e < E.
+static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
+                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st)
 {
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
   const dim3 grid((unsigned)((S + kWave - 1) / kWave), (unsigned)nblk), block(kWave, kFitSub);
   const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
-  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, E, S, 4, w.partial);
+  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 4, w.partial);
   hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done);
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
   const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   for (int it = 0; it < coarse; ++it) {
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, E, S, 16, w.eta, w.lam, w.done, w.partial);
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 16, w.eta, w.lam, w.done, w.partial);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done, 1e-6, 0);
   }
   for (int it = 0; it < 10; ++it) {   // converged columns skip their work; typically 3 passes do something
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, E, S, 1, w.eta, w.lam, w.done, w.partial);
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 1, w.eta, w.lam, w.done, w.partial);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done, 1e-6, 1);
   }
   hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
@@ -1601,13 +1601,16 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   return ED_OK;
 }
 
-ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
-                           void* stream_)
+// R/class_definition.R:107-113: a scalar subset.for.speed = n fits on rows seq(1, nrow, by = floor(nrow / n)),
+// i.e. 0-based exons 0, by, 2*by, ... -- a strided view of the count matrices.
+ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, int64_t by, double* d_phi,
+                                  double* d_expected, void* stream_)
 {
   if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_fit: NULL argument");
   hipStream_t st = (hipStream_t)stream_;
   const int64_t E = b->plan->E, S = b->S;
   if (E <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_fit: no exons");
+  if (by < 1) return ed_fail(ED_ERR_INVALID, "ed_batch_fit_subset: row step %lld < 1 (subset.for.speed larger than the number of exons?)", (long long)by);
   if (!b->fitw) {
     b->fitw = new (std::nothrow) FitWork;
     if (!b->fitw) return ed_fail(ED_ERR_NOMEM, "out of host memory");
@@ -1615,10 +1618,17 @@ ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_
   }
   b->stream = st;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
-  if (int rc = fit_columns(*b->fitw, d_test, S, 1, d_ref, E, S, d_phi, d_expected, st)) return rc;
+  const int64_t rows = (E - 1) / by + 1;
+  if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st)) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[6], st));
   b->have_fit_time = b->timing;
   return ED_OK;
+}
+
+ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
+                           void* stream_)
+{
+  return ed_batch_fit_subset(b, d_test, d_ref, 1, d_phi, d_expected, stream_);
 }
 
 ED_EXPORT const double* ed_batch_loglik(const ed_batch* b) { return (b && (b->keep_loglik || !b->fused)) ? b->d_loglik : nullptr; }

@@ -126,6 +126,10 @@ void ed_batch_destroy(ed_batch* batch);
  * d_test/d_ref: int32 [n_exons][n_samples] sample-minor DEVICE matrices. */
 int ed_batch_fit(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
                  void* stream);
+/* The same fit on every `by`-th exon only (exons 0, by, 2*by, ...): the scalar form of subset.for.speed,
+ * reference R/class_definition.R:107-113, where by = floor(n_exons / subset.for.speed).  by = 1 is ed_batch_fit. */
+int ed_batch_fit_subset(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, int64_t by, double* d_phi,
+                        double* d_expected, void* stream);
 
 /* Emissions + Viterbi + call segmentation for the whole batch.  All pointers are DEVICE pointers.
  * d_phi/d_expected: per-sample dispersion and expected proportion (from ed_batch_fit or given).

@@ -82,3 +82,34 @@ def test_fit_then_run_end_to_end(edlib, oracle):
         assert np.array_equal(ll[:, :, s].view(np.int64), np.ascontiguousarray(ell).view(np.int64))
         ep, _ = oracle.callcnvs(ell, chrom_off, start, end)
         assert np.array_equal(path[:, s].astype(np.int8), ep)
+
+
+def test_fit_subset_for_speed(edlib, oracle):
+    """Scalar subset.for.speed (R/class_definition.R:107-113): the fit sees rows seq(1, nrow, by = floor(nrow / n))
+    only.  Batched entry (by-strided view) and the per-sample mirror against the checker's MLE on those rows."""
+    from exomedepth_amd import synth
+    from exomedepth_amd._lib import check, lib
+    E, S, n_sub = 9001, 5, 700
+    by = E // n_sub
+    chrom_off, start, end = synth.exon_design(E, 3, 61)
+    test, ref, _, _, _ = synth.counts_numpy(chrom_off, S, 61, n_segments=3)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dphi = edlib.DeviceArray(np.zeros(S)); dexp = edlib.DeviceArray(np.zeros(S))
+    batch.fit(test, ref, dphi, dexp, by=by)
+    check(lib().ed_synchronize(None))
+    gphi, gexp = dphi.to_host(), dexp.to_host()
+    batch.close(); plan.close()
+    rows = np.arange(0, E, by)
+    assert rows.size == (E - 1) // by + 1
+    for s in range(S):
+        ophi, op, _, _ = oracle.fit_mle(test[rows, s], ref[rows, s])
+        assert abs(gphi[s] - ophi) / ophi < FIT_REL_TOL
+        assert abs(gexp[s] - op) / op < FIT_REL_TOL
+    x = edlib.ExomeDepth(test[:, 0].astype(float), ref[:, 0].astype(float), subset_for_speed=n_sub)
+    assert abs(x.phi[0] - gphi[0]) / gphi[0] < 1e-12 and x.phi.size == E
+    assert abs(x.expected[0] - gexp[0]) / gexp[0] < 1e-12
+    # vector form: explicit 1-based rows, non-existing ones dropped
+    idx = np.concatenate([rows + 1, [0, E + 5]])
+    y = edlib.ExomeDepth(test[:, 0].astype(float), ref[:, 0].astype(float), subset_for_speed=idx)
+    assert y.phi[0] == x.phi[0]
