@@ -382,8 +382,8 @@ __device__ __forceinline__ unsigned vit_step_q(double& v, double e, double t0, d
 __global__ void __launch_bounds__(kWave, ED_VIT_OCC)
 k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, double c0, double c1,
           const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off, int64_t S, int32_t C,
-          uint32_t* __restrict__ bpq, uint32_t* __restrict__ ppath, int32_t* __restrict__ counts,
-          const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom, int job_base)
+          uint32_t* __restrict__ bpq, uint8_t* __restrict__ last, const int32_t* __restrict__ job_off,
+          const int32_t* __restrict__ job_chrom, int job_base)
 {
   const int lane = threadIdx.x;
   const int j = lane & 3;
@@ -399,17 +399,12 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   const int c = job_chrom[jc];
   const int64_t lo = chrom_off[c], hi = chrom_off[c + 1];
   const int64_t m = hi - lo;
-  if (m <= 0) {
-    if (live && j == 0) counts[s * C + c] = 0;
-    continue;
-  }
+  if (m <= 0) continue;
   __syncthreads();   // the previous chromosome's readers are done with lds_lt
   const int col = (j == 1) ? 0 : ((j == 2) ? 2 : 1);
   const int64_t estride = 3 * S;                                  // doubles between consecutive exons
   const double2* __restrict__ ltp = reinterpret_cast<const double2*>(lt4) + (lo + c) * 4 + j;  // step i: ltp[i * 4]
-  uint32_t* __restrict__ bpc = bpq + (word_off[c] * S + s) * 4 + j;                            // word w: bpc[w * S * 4]
   const int64_t wstride = S * 4;
-  uint32_t* __restrict__ ppc = ppath + word_off[c] * S + s;   // packed states of word w: ppc[w * S]
   const double t0 = (j == 0 || j == 3) ? c0 : c1;
   double v = (j == 0 || j == 3) ? 0.0 : -HUGE_VAL;
 
@@ -487,50 +482,120 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
     const unsigned fw = vit_step_q(v, e, t0, l.x, l.y);
     st = quad_bcast_i<0>((int)fw);
   }
-  // ---- trace back (src/hmm.cpp:95-100) + call count ----
-  // All four lanes of the quad walk the same path; each holds the back-pointers of its own state, so the
-  // pointer to follow is a quad broadcast selected by the current state.  A call is pushed by the
-  // reference's summary loop (src/hmm.cpp:109-121) exactly where a run of a non-zero state ends, so the
-  // count is the number of positions q with tb[q] != tb[q+1], tb[q] != 0.
-  int count = 0, after = 0;
-  uint32_t pw = 0;   // Viterbi states of the current 16-exon word, 2 bits each
-  // the three states' pointer words of a 16-step word are broadcast across the quad once; per step the
-  // word of the current state is selected and its 2-bit field extracted
-  auto back = [&](uint32_t w0, uint32_t w1, uint32_t w2, int k) {
-    pw |= (uint32_t)st << (2 * k);
-    count += (st != after && st != 0) ? 1 : 0;
-    after = st;
-    const uint32_t wsel = (st == 0) ? w0 : ((st == 1) ? w1 : w2);
-    st = (int)((wsel >> (2 * k)) & 3u);
-  };
-  const int64_t nwfull = m / kVitTile;   // full 16-step words
-  if (m > nwfull * kVitTile) {
-    const int ww = (int)bpc[nwfull * wstride];
-    const uint32_t w0 = (uint32_t)quad_bcast_i<0>(ww), w1 = (uint32_t)quad_bcast_i<1>(ww), w2 = (uint32_t)quad_bcast_i<2>(ww);
-    for (int64_t i = m - 1; i >= nwfull * kVitTile; --i) back(w0, w1, w2, (int)(i & (kVitTile - 1)));
-    if (live && j == 0) ppc[nwfull * S] = pw;
-    pw = 0;
+  // the trace-back is data-parallel and lives in k_tb_maps / k_tb_chain / k_tb_paths
+  if (live && j == 0) last[(int64_t)c * S + s] = (uint8_t)st;
+  }   // chromosomes of the job
+}
+
+
+// ---- trace-back (src/hmm.cpp:95-100), data-parallel ------------------------------------------------------
+// tb[i-1] = from[i][tb[i]] is a composition of maps {0,1,2} -> {0,1,2}; composition is associative and the
+// objects are small integers, so regrouping it is exact.  A chromosome's back-pointers are stored 16 steps per
+// word (one word per state); word w therefore defines a map T_w from the state of its last exon to the state
+// of the last exon of word w-1:
+//   k_tb_maps   every (sample, word) in parallel: the three images of T_w (6 bits)
+//   k_tb_chain  one lane per chain: walk the ~m/16 maps from the last word down, leaving in each word's
+//               byte the state of that word's last exon (a 3-instruction dependent step per 16 exons)
+//   k_tb_paths  every (sample, word) in parallel: replay the 16 steps from the now known state, write the
+//               packed states, the byte-per-exon path of the interface, and count the calls (a call ends
+//               wherever a run of a non-zero state ends, src/hmm.cpp:109-121; integer atomics: exact)
+__device__ __forceinline__ uint32_t tb_pick(const uint4& w, int st) { return st == 0 ? w.x : (st == 1 ? w.y : w.z); }
+
+__global__ void __launch_bounds__(256)
+k_tb_maps(const uint32_t* __restrict__ bpq, const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off,
+          int64_t S, const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom, int job_base,
+          uint8_t* __restrict__ maps)
+{
+  const int64_t s = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t w = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int job = job_base + (int)blockIdx.z;
+  if (s >= S) return;
+  for (int jc = job_off[job]; jc < job_off[job + 1]; ++jc) {
+    const int c = job_chrom[jc];
+    const int64_t m = chrom_off[c + 1] - chrom_off[c];
+    if (w * kVitTile >= m) continue;
+    const int n = (int)((m - w * kVitTile < kVitTile) ? (m - w * kVitTile) : kVitTile);
+    const uint4 bw = reinterpret_cast<const uint4*>(bpq)[(word_off[c] + w) * S + s];
+    int x0 = 0, x1 = 1, x2 = 2;
+#pragma unroll
+    for (int k = kVitTile - 1; k >= 0; --k) {
+      if (k < n) {
+        x0 = (int)((tb_pick(bw, x0) >> (2 * k)) & 3u);
+        x1 = (int)((tb_pick(bw, x1) >> (2 * k)) & 3u);
+        x2 = (int)((tb_pick(bw, x2) >> (2 * k)) & 3u);
+      }
+    }
+    maps[(word_off[c] + w) * S + s] = (uint8_t)(x0 | (x1 << 2) | (x2 << 4));
   }
-  constexpr int kDepth = 4;   // back-pointer words kept in flight
-  uint32_t ring[kDepth];
+}
+
+__global__ void __launch_bounds__(kWave)
+k_tb_chain(const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off, int64_t S,
+           const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom, int job_base,
+           const uint8_t* __restrict__ last, uint8_t* __restrict__ maps)
+{
+  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const int job = job_base + (int)blockIdx.y;
+  if (s >= S) return;
+  for (int jc = job_off[job]; jc < job_off[job + 1]; ++jc) {
+    const int c = job_chrom[jc];
+    const int64_t m = chrom_off[c + 1] - chrom_off[c];
+    if (m <= 0) continue;
+    const int64_t nw = (m + kVitTile - 1) / kVitTile;
+    uint8_t* __restrict__ mp = maps + word_off[c] * S + s;   // word w: mp[w * S]
+    int st = last[(int64_t)c * S + s];
+    constexpr int kDepth = 16;   // maps in flight
+    uint32_t ring[kDepth];
 #pragma unroll
-  for (int d = 0; d < kDepth; ++d) ring[d] = (nwfull - 1 - d >= 0) ? (uint32_t)bpc[(nwfull - 1 - d) * wstride] : 0u;
-  for (int64_t wb = nwfull - 1; wb >= 0; wb -= kDepth) {
+    for (int d = 0; d < kDepth; ++d) ring[d] = (nw - 1 - d >= 0) ? mp[(nw - 1 - d) * S] : 0u;
+    for (int64_t wb = nw - 1; wb >= 0; wb -= kDepth) {
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) {
-      const int64_t wi = wb - d;
-      if (wi < 0) break;
-      const int ww = (int)ring[d];
-      if (wi - kDepth >= 0) ring[d] = (uint32_t)bpc[(wi - kDepth) * wstride];
-      const uint32_t w0 = (uint32_t)quad_bcast_i<0>(ww), w1 = (uint32_t)quad_bcast_i<1>(ww), w2 = (uint32_t)quad_bcast_i<2>(ww);
-#pragma unroll
-      for (int k = kVitTile - 1; k >= 0; --k) back(w0, w1, w2, k);
-      if (live && j == 0) ppc[wi * S] = pw;
-      pw = 0;
+      for (int d = 0; d < kDepth; ++d) {
+        const int64_t wi = wb - d;
+        if (wi >= 0) {
+          const uint32_t mw = ring[d];
+          if (wi - kDepth >= 0) ring[d] = mp[(wi - kDepth) * S];
+          mp[wi * S] = (uint8_t)st;               // state of word wi's last exon
+          st = (int)((mw >> (2 * st)) & 3u);      // ... and of word wi-1's
+        }
+      }
     }
   }
-  if (live && j == 0) counts[s * C + c] = count;
-  }   // chromosomes of the job
+}
+
+__global__ void __launch_bounds__(256)
+k_tb_paths(const uint32_t* __restrict__ bpq, const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off,
+           int64_t S, int32_t C, const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom, int job_base,
+           const uint8_t* __restrict__ maps, uint32_t* __restrict__ ppath, uint8_t* __restrict__ path,
+           int32_t* __restrict__ counts)
+{
+  const int64_t s = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t w = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int job = job_base + (int)blockIdx.z;
+  if (s >= S) return;
+  for (int jc = job_off[job]; jc < job_off[job + 1]; ++jc) {
+    const int c = job_chrom[jc];
+    const int64_t lo = chrom_off[c], m = chrom_off[c + 1] - lo;
+    if (w * kVitTile >= m) continue;
+    const int n = (int)((m - w * kVitTile < kVitTile) ? (m - w * kVitTile) : kVitTile);
+    const uint4 bw = reinterpret_cast<const uint4*>(bpq)[(word_off[c] + w) * S + s];
+    int st = maps[(word_off[c] + w) * S + s];                 // state of exon 16w + n - 1
+    int count = ((w + 1) * kVitTile >= m && st != 0) ? 1 : 0;  // the chromosome's last exon against the dummy end state 0
+    uint32_t pw = 0;
+    uint8_t* __restrict__ o = path + (lo + w * kVitTile) * S + s;
+#pragma unroll
+    for (int k = kVitTile - 1; k >= 0; --k) {
+      if (k < n) {
+        pw |= (uint32_t)st << (2 * k);
+        o[(int64_t)k * S] = (uint8_t)st;
+        const int prev = (int)((tb_pick(bw, st) >> (2 * k)) & 3u);   // state of exon 16w + k - 1
+        if ((k > 0 || w > 0) && prev != st && prev != 0) ++count;
+        st = prev;
+      }
+    }
+    ppath[(word_off[c] + w) * S + s] = pw;
+    if (count) atomicAdd(&counts[s * C + c], count);
+  }
 }
 
 }  // namespace
@@ -1037,6 +1102,8 @@ struct ed_batch {
   uint8_t* d_path = nullptr;
   uint32_t* d_bp = nullptr;      // [n_words][S][4] packed back-pointers (16 steps x 2 bits per quad lane)
   uint32_t* d_ppath = nullptr;   // [n_words][S] packed Viterbi states (16 exons x 2 bits)
+  uint8_t* d_maps = nullptr;     // [n_words][S] trace-back maps, then the state of each word's last exon
+  uint8_t* d_last = nullptr;     // [C][S] state of each chain's last exon (end of the forward pass)
   int32_t* d_job_off = nullptr;  // [n_jobs + 1]
   int32_t* d_job_chrom = nullptr;  // chromosomes in job order
   int64_t* d_seg = nullptr;        // emission segments in job order: (first workgroup, first cell, end cell) x n_jobs
@@ -1340,6 +1407,8 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   A((void**)&b->d_path, (size_t)E * S);
   A((void**)&b->d_bp, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4 * 4);
   A((void**)&b->d_ppath, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4);
+  A((void**)&b->d_maps, (size_t)std::max<int64_t>(plan->n_words, 1) * S);
+  A((void**)&b->d_last, (size_t)std::max<int64_t>(C, 1) * S);
   A((void**)&b->d_consts, (size_t)9 * S * 8);
   A((void**)&b->d_cflags, (size_t)3 * S * 4);
   A((void**)&b->d_counts, (size_t)S * std::max<int64_t>(C, 1) * 4);
@@ -1450,7 +1519,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -1520,15 +1589,22 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
                            b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, b->d_loglik, b->d_nerr);
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
       HIP_TRY(hipStreamWaitEvent(b->side, b->job_ev[g], 0));
+      const dim3 gw((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)(j1 - j0));
       hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
                          b->side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
-                         b->d_ppath, b->d_counts, b->d_job_off, b->d_job_chrom, j0);
+                         b->d_last, b->d_job_off, b->d_job_chrom, j0);
+      hipLaunchKernelGGL(k_tb_maps, gw, dim3(256), 0, b->side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, b->d_job_off,
+                         b->d_job_chrom, j0, b->d_maps);
+      hipLaunchKernelGGL(k_tb_chain, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)(j1 - j0)), dim3(kWave), 0, b->side,
+                         p->d_chrom_off, p->d_tile_off, S, b->d_job_off, b->d_job_chrom, j0, b->d_last, b->d_maps);
+      hipLaunchKernelGGL(k_tb_paths, gw, dim3(256), 0, b->side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, C, b->d_job_off,
+                         b->d_job_chrom, j0, b->d_maps, b->d_ppath, b->d_path, b->d_counts);
     }
     if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));   // all emissions issued and done on the main stream
     HIP_TRY(hipEventRecord(b->join_ev, b->side));
     HIP_TRY(hipStreamWaitEvent(st, b->join_ev, 0));
   }
-  if (C > 0 && cells > 0 && p->max_words > 0)
+  if (b->fused && C > 0 && cells > 0 && p->max_words > 0)   // (the two-kernel path writes the byte path in k_tb_paths)
     hipLaunchKernelGGL(k_path_expand, dim3((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)C), dim3(256),
                        0, st, b->d_ppath, p->d_chrom_off, p->d_tile_off, S, b->d_path);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
