@@ -366,7 +366,8 @@ __device__ __forceinline__ unsigned vit_step_q(double& v, double e, double t0, d
   const double c0 = (e + v0) + t0;
   const double c1 = (e + v1) + t1;
   const double c2 = (e + v2) + t2;
-  const double best = __builtin_fmax(__builtin_fmax(__builtin_fmax(NI, c0), c1), c2);
+  // maxNum ignores NaN operands and NI is never NaN, so any grouping gives the same value; this one is two deep
+  const double best = __builtin_fmax(__builtin_fmax(NI, c0), __builtin_fmax(c1, c2));
   unsigned fw = (c0 == best) ? 0u : ((c1 == best) ? 1u : 2u);
   if (best == NI) fw = 0u;
   v = best;
@@ -419,22 +420,27 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
   // tiles so that ring slots and LDS buffers are compile-time; the last (possibly partial) tiles take the
   // guarded instance, whose guards are scalar branches.
   constexpr int kRing = 2 * kVitTile;
-  const double* __restrict__ emb = loglik + lo * 3 * S;                                    // wave-uniform
-  const uint32_t eoff = (uint32_t)(col * S + s);                                           // lane part
-  uint32_t* __restrict__ bpb = bpq + word_off[c] * S * 4;                                  // wave-uniform
-  const uint32_t boff = (uint32_t)(s * 4 + j);
+  const char* __restrict__ emb = reinterpret_cast<const char*>(loglik + lo * 3 * S);       // wave-uniform
+  const uint32_t eoff = (uint32_t)((col * S + s) * 8);                                     // lane part, bytes (< 2^32)
+  const int64_t ebytes = estride * 8;                                                      // bytes between exons
+  char* __restrict__ bpb = reinterpret_cast<char*>(bpq + word_off[c] * S * 4);            // wave-uniform
+  const uint32_t boff = (uint32_t)((s * 4 + j) * 4);
+  const int64_t wbytes = wstride * 4;
   const double2* __restrict__ ltw = reinterpret_cast<const double2*>(lt4) + (lo + c) * 4;  // wave-level view
   const int m32 = (int)m;   // chromosome lengths are int32 (chrom_off); 32-bit so that the clamp is one s_min_i32
-  auto em_at = [&](int i) { return emb[(int64_t)(i < m32 ? i : m32 - 1) * estride + eoff]; };
+  // scalar base + 32-bit lane offset: the load needs no vector address arithmetic
+  auto em_ld = [&](const char* row) { return *reinterpret_cast<const double*>(row + eoff); };
+  auto em_at = [&](int i) { return em_ld(emb + (int64_t)(i < m32 ? i : m32 - 1) * ebytes); };
   double er[kRing];
   double2 stg = ltw[lane];
 #pragma unroll
   for (int k = 0; k < kRing; ++k) er[k] = em_at(k);
   (&lds_lt[0][0][0])[lane] = stg;
   __syncthreads();
+  const char* nxt = emb + (int64_t)kRing * ebytes;   // row of the next re-load in the unclamped (safe) region
   auto tile = [&](auto par, auto full, int t, int nsteps) {
     constexpr int P = decltype(par)::value;
-    constexpr bool kFull = decltype(full)::value;
+    constexpr bool kFull = decltype(full)::value;   // full tile whose re-loads (16t+k+kRing) all lie inside the chromosome
     stg = ltw[(t + 1) * 64 + lane];
     uint32_t w = 0;
 #pragma unroll
@@ -451,24 +457,31 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
           // tile to the store below (keeping 3 doubles per step alive) and turns the shifts into constant tables
           asm("" : "+v"(fw));
           w |= fw << (2 * kk);
-          er[P * kVitTile + kk] = em_at(t * kVitTile + kk + kRing);
+          if (kFull) {
+            er[P * kVitTile + kk] = em_ld(nxt);
+            nxt += ebytes;
+          } else {
+            er[P * kVitTile + kk] = em_at(t * kVitTile + kk + kRing);
+          }
         }
       }
     }
-    bpb[(int64_t)t * wstride + boff] = w;   // idle quads shadow sample S-1: same value to the same address
+    // idle quads shadow sample S-1: same value to the same address
+    *reinterpret_cast<uint32_t*>(bpb + (int64_t)t * wbytes + boff) = w;
     (&lds_lt[P ^ 1][0][0])[lane] = stg;
     __syncthreads();
   };
   {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    const int nfull = m32 / kVitTile, ntile = (m32 + kVitTile - 1) / kVitTile;
+    const int ntile = (m32 + kVitTile - 1) / kVitTile;
+    const int tsafe = (m32 >= kRing ? (m32 - kRing) / kVitTile : 0) & ~1;   // tiles t < tsafe never re-load past exon m-1
     int t = 0;
-    for (; t + 2 <= nfull; t += 2) {
+    for (; t < tsafe; t += 2) {
       tile(I0{}, std::true_type{}, t, kVitTile);
       tile(I1{}, std::true_type{}, t + 1, kVitTile);
     }
-    for (; t < ntile; ++t) {   // at most two: a last full tile and/or the partial one
+    for (; t < ntile; ++t) {   // the last few tiles (at most four): clamped re-loads, guarded steps
       const int nst = (m32 - t * kVitTile < kVitTile) ? (m32 - t * kVitTile) : kVitTile;
       if (t & 1) tile(I1{}, std::false_type{}, t, nst);
       else tile(I0{}, std::false_type{}, t, nst);
@@ -494,8 +507,8 @@ k_viterbi(const double* __restrict__ loglik, const double* __restrict__ lt4, dou
 // word (one word per state); word w therefore defines a map T_w from the state of its last exon to the state
 // of the last exon of word w-1:
 //   k_tb_maps   every (sample, word) in parallel: the three images of T_w (6 bits)
-//   k_tb_chain  one lane per chain: walk the ~m/16 maps from the last word down, leaving in each word's
-//               byte the state of that word's last exon (a 3-instruction dependent step per 16 exons)
+//   k_tb_chain  one lane per chain: walk the ~m/16 maps from the last word down, recording the state of each
+//               word's last exon (a 3-instruction dependent step per 16 exons)
 //   k_tb_paths  every (sample, word) in parallel: replay the 16 steps from the now known state, write the
 //               packed states, the byte-per-exon path of the interface, and count the calls (a call ends
 //               wherever a run of a non-zero state ends, src/hmm.cpp:109-121; integer atomics: exact)
@@ -529,10 +542,12 @@ k_tb_maps(const uint32_t* __restrict__ bpq, const int32_t* __restrict__ chrom_of
   }
 }
 
+// States are left packed 16 words per 32-bit word (ent, rows (word_off[c] >> 4) + c + (w >> 4)): one store per 16
+// steps, issued after the next group's loads, so the dependent walk never waits on a store.
 __global__ void __launch_bounds__(kWave)
 k_tb_chain(const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off, int64_t S,
            const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom, int job_base,
-           const uint8_t* __restrict__ last, uint8_t* __restrict__ maps)
+           const uint8_t* __restrict__ last, const uint8_t* __restrict__ maps, uint32_t* __restrict__ ent)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
   const int job = job_base + (int)blockIdx.y;
@@ -541,24 +556,33 @@ k_tb_chain(const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ wo
     const int c = job_chrom[jc];
     const int64_t m = chrom_off[c + 1] - chrom_off[c];
     if (m <= 0) continue;
-    const int64_t nw = (m + kVitTile - 1) / kVitTile;
-    uint8_t* __restrict__ mp = maps + word_off[c] * S + s;   // word w: mp[w * S]
+    const int nw = (int)((m + kVitTile - 1) / kVitTile);
+    const int ng = (nw + 15) / 16;
+    const uint8_t* __restrict__ mp = maps + word_off[c] * S + s;              // word w: mp[w * S]
+    uint32_t* __restrict__ ep = ent + ((word_off[c] >> 4) + c) * S + s;       // group g: ep[g * S]
     int st = last[(int64_t)c * S + s];
-    constexpr int kDepth = 16;   // maps in flight
-    uint32_t ring[kDepth];
+    uint32_t cur[16], nxt[16];
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) ring[d] = (nw - 1 - d >= 0) ? mp[(nw - 1 - d) * S] : 0u;
-    for (int64_t wb = nw - 1; wb >= 0; wb -= kDepth) {
+    for (int k = 0; k < 16; ++k) {
+      const int w = (ng - 1) * 16 + k;
+      cur[k] = (w < nw) ? mp[(int64_t)w * S] : 0u;
+    }
+    for (int g = ng - 1; g >= 0; --g) {
+      if (g > 0) {
 #pragma unroll
-      for (int d = 0; d < kDepth; ++d) {
-        const int64_t wi = wb - d;
-        if (wi >= 0) {
-          const uint32_t mw = ring[d];
-          if (wi - kDepth >= 0) ring[d] = mp[(wi - kDepth) * S];
-          mp[wi * S] = (uint8_t)st;               // state of word wi's last exon
-          st = (int)((mw >> (2 * st)) & 3u);      // ... and of word wi-1's
+        for (int k = 0; k < 16; ++k) nxt[k] = mp[(int64_t)((g - 1) * 16 + k) * S];
+      }
+      uint32_t pk = 0;
+#pragma unroll
+      for (int k = 15; k >= 0; --k) {
+        if (g * 16 + k < nw) {
+          pk |= (uint32_t)st << (2 * k);                  // state of word (16g + k)'s last exon
+          st = (int)((cur[k] >> (2 * st)) & 3u);          // ... and of the word before it
         }
       }
+      ep[(int64_t)g * S] = pk;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
     }
   }
 }
@@ -566,7 +590,7 @@ k_tb_chain(const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ wo
 __global__ void __launch_bounds__(256)
 k_tb_paths(const uint32_t* __restrict__ bpq, const int32_t* __restrict__ chrom_off, const int64_t* __restrict__ word_off,
            int64_t S, int32_t C, const int32_t* __restrict__ job_off, const int32_t* __restrict__ job_chrom, int job_base,
-           const uint8_t* __restrict__ maps, uint32_t* __restrict__ ppath, uint8_t* __restrict__ path,
+           const uint32_t* __restrict__ ent, uint32_t* __restrict__ ppath, uint8_t* __restrict__ path,
            int32_t* __restrict__ counts)
 {
   const int64_t s = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -579,7 +603,7 @@ k_tb_paths(const uint32_t* __restrict__ bpq, const int32_t* __restrict__ chrom_o
     if (w * kVitTile >= m) continue;
     const int n = (int)((m - w * kVitTile < kVitTile) ? (m - w * kVitTile) : kVitTile);
     const uint4 bw = reinterpret_cast<const uint4*>(bpq)[(word_off[c] + w) * S + s];
-    int st = maps[(word_off[c] + w) * S + s];                 // state of exon 16w + n - 1
+    int st = (int)((ent[((word_off[c] >> 4) + c + (w >> 4)) * S + s] >> (2 * (int)(w & 15))) & 3u);   // state of exon 16w + n - 1
     int count = ((w + 1) * kVitTile >= m && st != 0) ? 1 : 0;  // the chromosome's last exon against the dummy end state 0
     uint32_t pw = 0;
     uint8_t* __restrict__ o = path + (lo + w * kVitTile) * S + s;
@@ -1102,7 +1126,8 @@ struct ed_batch {
   uint8_t* d_path = nullptr;
   uint32_t* d_bp = nullptr;      // [n_words][S][4] packed back-pointers (16 steps x 2 bits per quad lane)
   uint32_t* d_ppath = nullptr;   // [n_words][S] packed Viterbi states (16 exons x 2 bits)
-  uint8_t* d_maps = nullptr;     // [n_words][S] trace-back maps, then the state of each word's last exon
+  uint8_t* d_maps = nullptr;     // [n_words][S] trace-back maps of the 16-step words
+  uint32_t* d_ent = nullptr;     // [n_words / 16 + C + 1][S] state of each word's last exon, 16 words per u32
   uint8_t* d_last = nullptr;     // [C][S] state of each chain's last exon (end of the forward pass)
   int32_t* d_job_off = nullptr;  // [n_jobs + 1]
   int32_t* d_job_chrom = nullptr;  // chromosomes in job order
@@ -1408,6 +1433,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   A((void**)&b->d_bp, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4 * 4);
   A((void**)&b->d_ppath, (size_t)std::max<int64_t>(plan->n_words, 1) * S * 4);
   A((void**)&b->d_maps, (size_t)std::max<int64_t>(plan->n_words, 1) * S);
+  A((void**)&b->d_ent, (size_t)(plan->n_words / 16 + C + 1) * S * 4);
   A((void**)&b->d_last, (size_t)std::max<int64_t>(C, 1) * S);
   A((void**)&b->d_consts, (size_t)9 * S * 8);
   A((void**)&b->d_cflags, (size_t)3 * S * 4);
@@ -1519,7 +1545,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -1596,9 +1622,9 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
       hipLaunchKernelGGL(k_tb_maps, gw, dim3(256), 0, b->side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, b->d_job_off,
                          b->d_job_chrom, j0, b->d_maps);
       hipLaunchKernelGGL(k_tb_chain, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)(j1 - j0)), dim3(kWave), 0, b->side,
-                         p->d_chrom_off, p->d_tile_off, S, b->d_job_off, b->d_job_chrom, j0, b->d_last, b->d_maps);
+                         p->d_chrom_off, p->d_tile_off, S, b->d_job_off, b->d_job_chrom, j0, b->d_last, b->d_maps, b->d_ent);
       hipLaunchKernelGGL(k_tb_paths, gw, dim3(256), 0, b->side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, C, b->d_job_off,
-                         b->d_job_chrom, j0, b->d_maps, b->d_ppath, b->d_path, b->d_counts);
+                         b->d_job_chrom, j0, b->d_ent, b->d_ppath, b->d_path, b->d_counts);
     }
     if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));   // all emissions issued and done on the main stream
     HIP_TRY(hipEventRecord(b->join_ev, b->side));
