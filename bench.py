@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--fit", type=int, default=1, help="1 (default): the step includes the per-sample dispersion fit (configs[2]); 0: phi given (configs[1] style)")
     ap.add_argument("--fused", type=int, default=0, help="1: emissions + Viterbi as one kernel (csrc/edfused.inc)")
     ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
+    ap.add_argument("--phi-bins", type=int, default=1, help="> 1: the depth-binned dispersion model (phi.bins, csrc/edbins.inc); "
+                    "an optional mode, not the headline configuration")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -139,9 +141,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     phi_fit = torch.empty(S, dtype=torch.float64, device=dev)
     p_fit = torch.empty(S, dtype=torch.float64, device=dev)
+    phib_fit = torch.empty((max(args.phi_bins, 1), S), dtype=torch.float64, device=dev)
+    edges_fit = torch.empty((max(args.phi_bins, 1) + 1, S), dtype=torch.float64, device=dev)
 
     def step():
-        if args.fit:
+        if args.phi_bins > 1:
+            batch.fit_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit, stream=stream)
+            batch.run_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit, 1.0, stream=stream)
+        elif args.fit:
             batch.fit(test, ref, phi_fit, p_fit, stream=stream)
             batch.run(test, ref, phi_fit, p_fit, 1.0, stream=stream)
         else:
@@ -196,7 +203,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
-                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused),
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused), "phi_bins": args.phi_bins,
                        "parallelism": "samples sharded, %d rank(s); call tables gathered over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": "k_emit_viterbi" if args.fused else "k_emit_batch", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -251,6 +251,42 @@ class Batch:
         self._keep = keep  # keep temporaries alive until the next run
         check(lib().ed_batch_run(self.handle, pt, pr, pp, pe, float(mixture), C.c_void_p(stream or 0)))
 
+    def fit_bins(self, test, ref, phi_bins, phi_bins_out, edges_out, expected_out, stream=None):
+        """phi.bins > 1 (reference R/class_definition.R:120-147): per sample the depth levels of the reference
+        counts (edges_out: (phi_bins + 1, n_samples) complete.bins), one dispersion per level (phi_bins_out:
+        (phi_bins, n_samples)) and the common expected proportion.  Raises EdError("Binning did not happen
+        properly ...") like the reference's stop() when a level is empty.  Synchronous."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi_bins_out, np.float64, keep)
+        pg = _device_pointer(edges_out, np.float64, keep)
+        pe = _device_pointer(expected_out, np.float64, keep)
+        self._keep = keep
+        check(lib().ed_batch_fit_bins(self.handle, pt, pr, int(phi_bins), pp, pg, pe, C.c_void_p(stream or 0)))
+
+    def run_bins(self, test, ref, phi_bins, phi_bins_dev, edges_dev, expected, mixture=1.0, stream=None):
+        """run() with the per-exon dispersion phi.linear of the phi.bins > 1 model (interpolated on the fly)."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi_bins_dev, np.float64, keep)
+        pg = _device_pointer(edges_dev, np.float64, keep)
+        pe = _device_pointer(expected, np.float64, keep)
+        self._keep = keep
+        check(lib().ed_batch_run_bins(self.handle, pt, pr, int(phi_bins), pp, pg, pe, float(mixture), C.c_void_p(stream or 0)))
+
+    def phi_linear(self, ref, phi_bins, phi_bins_dev, edges_dev):
+        """(n_exons, n_samples) host array: the S4 `phi` slot of the phi.bins > 1 model."""
+        keep = []
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi_bins_dev, np.float64, keep)
+        pg = _device_pointer(edges_dev, np.float64, keep)
+        out = DeviceArray(np.zeros((self.plan.n_exons, self.n_samples)))
+        check(lib().ed_batch_phi_linear(self.handle, pr, int(phi_bins), pp, pg, out.ptr, None))
+        check(lib().ed_synchronize(None))
+        return out.to_host().reshape(self.plan.n_exons, self.n_samples)
+
     # ---- results ----
     def n_calls(self):
         n = C.c_int64(0)
@@ -330,7 +366,8 @@ class ExomeDepth:
     phi / expected: if given, the fixed dispersion and expected proportion (the reference gets them
     from aod::betabin, :118, :168); if omitted they are fitted on the GPU (ed_batch_fit)."""
 
-    def __init__(self, test, reference, phi=None, expected=None, prop_tumor=1.0, subset_for_speed=None, verbose=False):
+    def __init__(self, test, reference, phi=None, expected=None, prop_tumor=1.0, subset_for_speed=None, phi_bins=1,
+                 verbose=False):
         test = np.asarray(test, dtype=np.float64)
         reference = np.asarray(reference, dtype=np.float64)
         if test.size != reference.size:
@@ -347,6 +384,11 @@ class ExomeDepth:
                 print("It looks like the test samples has only %d bins with more than 5 reads." % np.sum(test > 5))
             return
         n = test.size
+        if (phi is None or expected is None) and phi_bins != 1:        # R/class_definition.R:120-147
+            if subset_for_speed is not None:
+                raise ValueError("Subset for speed option is not compatible with variable phi. This will be fixed later on "
+                                 "but for now please adapt your code.")
+            phi, expected = fit_betabin_bins(_as_r_integer(test), _as_r_integer(reference), int(phi_bins))
         if phi is None or expected is None:
             rows = np.arange(n)
             if subset_for_speed is not None:                           # R/class_definition.R:107-113
@@ -400,17 +442,38 @@ class ExomeDepth:
             self.expected = self.expected[order]
         self.annotations = {"name": name, "chromosome": chrom_sorted, "start": start, "end": end}
         self.cor_test_reference = float(np.corrcoef(self.test, self.reference)[0, 1])
-        plan = Plan(chrom_off, start, end, transition_probability, expected_CNV_length)
-        batch = Batch(plan, 1)
-        try:
-            # the likelihood is recomputed on the device from the same inputs (bit-identical to the slot)
-            batch.run(_as_r_integer(self.test).reshape(n, 1), _as_r_integer(self.reference).reshape(n, 1),
-                      self.phi[:1], self.expected[:1])
-            raw = batch.calls()
-            self.Viterbi_path = batch.path()[:, 0].astype(np.int64)
-        finally:
-            batch.close()
-            plan.close()
+        constant = bool(np.all(self.phi == self.phi[0]) and np.all(self.expected == self.expected[0]))
+        if constant:
+            plan = Plan(chrom_off, start, end, transition_probability, expected_CNV_length)
+            batch = Batch(plan, 1)
+            try:
+                # the likelihood is recomputed on the device from the same inputs (bit-identical to the slot)
+                batch.run(_as_r_integer(self.test).reshape(n, 1), _as_r_integer(self.reference).reshape(n, 1),
+                          self.phi[:1], self.expected[:1])
+                raw = batch.calls()
+                self.Viterbi_path = batch.path()[:, 0].astype(np.int64)
+            finally:
+                batch.close()
+                plan.close()
+        else:
+            # per-exon phi (phi.bins > 1) or expected: the likelihood slot itself goes through the .Call-shaped
+            # entry, chromosome by chromosome, exactly as R/class_definition.R:343-374 does
+            tp = transition_probability
+            T = np.array([[1. - tp, tp / 2., tp / 2.], [0.5, 0.5, 0.], [0.5, 0., 0.5]])
+            raw = []
+            self.Viterbi_path = np.zeros(n, dtype=np.int64)
+            for c in range(len(chrom_off) - 1):
+                lo, hi = int(chrom_off[c]), int(chrom_off[c + 1])
+                if hi <= lo:
+                    continue
+                ll = np.vstack([[-np.inf, 0., -np.inf], self.likelihood[lo:hi][:, [1, 0, 2]], [-100., 0., -100.]])
+                pos = np.concatenate([[start[lo] - 2 * expected_CNV_length], start[lo:hi],
+                                      [end[hi - 1] + 2 * expected_CNV_length]])
+                res = viterbi_hmm(T, ll, _as_r_integer(pos.astype(np.float64)), expected_CNV_length)
+                self.Viterbi_path[lo:hi] = res["Viterbi.path"][1:-1]
+                for r in res["calls"]:
+                    raw.append({"start_exon": int(r["start.p"]) - 2 + lo, "end_exon": int(r["end.p"]) - 2 + lo,
+                                "type": int(r["type"]), "nexons": int(r["nexons"])})
         calls = []
         total = self.test + self.reference
         for r in raw:
@@ -478,6 +541,27 @@ def _signif(x, digits):
     from math import floor, log10
     e = digits - 1 - int(floor(log10(abs(x))))
     return round(x * 10 ** e) / 10 ** e if e >= 0 else round(x / 10 ** (-e)) * 10 ** (-e)
+
+
+def fit_betabin_bins(test, reference, phi_bins):
+    """phi.bins > 1 for one sample on the GPU: returns (phi.linear per exon, expected)."""
+    test = _i32(test)
+    reference = _i32(reference)
+    n = test.size
+    plan = Plan(np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32) + 1)
+    batch = Batch(plan, 1)
+    try:
+        phib = DeviceArray(np.zeros(phi_bins))
+        edges = DeviceArray(np.zeros(phi_bins + 1))
+        exp = DeviceArray(np.zeros(1))
+        t = DeviceArray(test.reshape(n, 1))
+        r = DeviceArray(reference.reshape(n, 1))
+        batch.fit_bins(t, r, phi_bins, phib, edges, exp)
+        phi_lin = batch.phi_linear(r, phi_bins, phib, edges)[:, 0]
+        return phi_lin, float(exp.to_host()[0])
+    finally:
+        batch.close()
+        plan.close()
 
 
 def fit_betabin(test, reference):

@@ -1561,10 +1561,19 @@ ED_EXPORT int ed_batch_enable_timing(ed_batch* b, int enable)
   return ED_OK;
 }
 
-ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
-                           const double* d_expected, double mixture, void* stream_)
+namespace {
+// edbins.inc (phi.bins > 1): emissions with a per-exon dispersion interpolated from the per-level estimates
+__global__ void k_emit_bins(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int B, const double* __restrict__ edges,
+                            const double* __restrict__ phib, const double* __restrict__ expected, double mixture, int64_t E, int64_t S,
+                            double* __restrict__ loglik, unsigned long long* __restrict__ nerr);
+}
+
+// bins > 0: depth-binned dispersion (d_phi = phi.estimates [bins][S], d_edges = complete.bins [(bins + 1)][S])
+static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
+                          const double* d_expected, double mixture, void* stream_, int bins, const double* d_edges)
 {
   if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_run: NULL argument");
+  if (bins > 0 && b->fused) return ed_fail(ED_ERR_STATE, "ed_batch_run_bins: not available in fused mode");
   hipStream_t st = (hipStream_t)stream_;
   const ed_plan* p = b->plan;
   const int64_t E = p->E, S = b->S;
@@ -1573,8 +1582,9 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 8, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
-                     b->d_consts, b->d_cflags);
+  if (bins == 0)
+    hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
+                       b->d_consts, b->d_cflags);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int64_t cells = E * S;
   if (b->fused) {
@@ -1605,8 +1615,11 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
       // One launch per group, except that a group following another starts with a short separate launch: the
       // previous group's Viterbi workgroups (side stream) are dispatched into the slots freed at that launch
       // boundary instead of queueing behind this group's thousands of pending workgroups.
-      const int64_t blk0 = b->seg[3 * j0], nblk = b->seg[3 * j1] - blk0;
+      const int64_t blk0 = b->seg[3 * j0], nblk = (bins > 0) ? 0 : b->seg[3 * j1] - blk0;
       const int64_t head = (g > 0) ? std::min<int64_t>(nblk, kEmitHeadBlocks) : 0;
+      if (bins > 0 && g == 0)   // one launch over every cell; the Viterbi groups follow it
+        hipLaunchKernelGGL(k_emit_bins, dim3((unsigned)((cells + kEmitBlock - 1) / kEmitBlock)), dim3(kEmitBlock), 0, st, d_test,
+                           d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S, b->d_loglik, b->d_nerr);
       if (head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
                            b->d_seg, b->n_jobs, blk0, S, b->d_loglik, b->d_nerr);
@@ -1644,6 +1657,12 @@ ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_
   b->ran = true;
   b->have_run_times = b->timing;
   return ED_OK;
+}
+
+ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
+                           const double* d_expected, double mixture, void* stream_)
+{
+  return batch_run_impl(b, d_test, d_ref, d_phi, d_expected, mixture, stream_, 0, nullptr);
 }
 
 // workspace of the column-wise beta-binomial fit (shared by ed_batch_fit and ed_select_reference_set)
@@ -1858,3 +1877,4 @@ ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
 }
 
 #include "edrefset.inc"
+#include "edbins.inc"

@@ -131,6 +131,23 @@ int ed_batch_fit(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, d
 int ed_batch_fit_subset(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, int64_t by, double* d_phi,
                         double* d_expected, void* stream);
 
+/* Depth-binned dispersion, `phi.bins > 1` of the reference's initialiser (R/class_definition.R:120-147), per sample:
+ *   edges     double [(phi_bins + 1)][n_samples]  complete.bins: seq(0, q85, by = q85/(phi_bins-1)), max + 1  (:124-126)
+ *   phi_bins  double [phi_bins][n_samples]        one dispersion per level of depth.quant, common intercept     (:135-139)
+ *   expected  double [n_samples]                  fitted(mod)
+ * 2 <= phi_bins <= 8.  Fails with "Binning did not happen properly" (:130-133) if a level of some sample is empty.
+ * Synchronises the stream before returning (the level check is done on the host). */
+int ed_batch_fit_bins(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, int phi_bins, double* d_phi_bins,
+                      double* d_edges, double* d_expected, void* stream);
+/* ed_batch_run with the per-exon dispersion phi.linear = approxfun(bin mid-points, phi.estimates)(reference)
+ * (:141-147) evaluated on the fly; everything downstream of the emissions is ed_batch_run's.  Not available in
+ * fused mode. */
+int ed_batch_run_bins(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, int phi_bins, const double* d_phi_bins,
+                      const double* d_edges, const double* d_expected, double mixture, void* stream);
+/* The S4 `phi` slot of that model: d_phi_out double [n_exons][n_samples] = phi.linear. */
+int ed_batch_phi_linear(ed_batch* batch, const int32_t* d_ref, int phi_bins, const double* d_phi_bins, const double* d_edges,
+                        double* d_phi_out, void* stream);
+
 /* Emissions + Viterbi + call segmentation for the whole batch.  All pointers are DEVICE pointers.
  * d_phi/d_expected: per-sample dispersion and expected proportion (from ed_batch_fit or given).
  * Asynchronous on `stream`; results are valid after the stream is synchronised (the accessors that

@@ -58,6 +58,8 @@ def lib():
         L.edo_psi_v.restype = None
         L.edo_fit_mle.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.edo_fit_mle.restype = C.c_int
+        L.edo_fit_mle_groups.argtypes = [_ip, _ip, _ip, C.c_long, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.edo_fit_mle_groups.restype = C.c_int
         L.edo_fit_nm.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.edo_fit_nm.restype = C.c_int
         _LIB = L
@@ -159,6 +161,18 @@ def fit_mle(test, ref):
     phi, p, ll = C.c_double(), C.c_double(), C.c_double()
     it = lib().edo_fit_mle(test, ref, test.size, C.byref(phi), C.byref(p), C.byref(ll))
     return phi.value, p.value, ll.value, it
+
+
+def fit_mle_groups(test, ref, grp, n_groups):
+    """High-precision MLE of (phi_1..phi_B, p) for  cbind(test, reference) ~ 1, random = ~ depth.quant
+    (phi.bins > 1, reference R/class_definition.R:135-139; parity unpinned).  grp: 0-based group of each row."""
+    test = _i32(test); ref = _i32(ref); grp = _i32(grp)
+    phi = np.zeros(n_groups)
+    p, ll = C.c_double(), C.c_double()
+    it = lib().edo_fit_mle_groups(test, ref, grp, test.size, n_groups, phi, C.byref(p), C.byref(ll))
+    if it < 0:
+        raise ValueError("edo_fit_mle_groups: nothing to fit (%d)" % it)
+    return phi, p.value, ll.value, it
 
 
 def fit_nm(test, ref):

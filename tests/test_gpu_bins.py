@@ -1,0 +1,126 @@
+"""Depth-binned dispersion (`phi.bins > 1`, reference R/class_definition.R:120-147) through the C-ABI.
+
+Parity status.  Binning, interpolation and emissions are restated from the R/C sources and are compared exactly
+(complete.bins and phi.linear bit for bit against oracle/bins_oracle.py; the likelihood bit for bit against the
+checker's get_loglike_matrix fed the same per-exon phi).  The per-level dispersions come from aod::betabin in the
+reference (not in the reference tree): UNPINNED, compared at FIT_REL_TOL with the checker's long-double MLE of the
+documented likelihood.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import bits
+
+pytestmark = pytest.mark.gpu
+
+FIT_REL_TOL = 1e-7
+
+
+def _case(E, S, C, seed, depth=90.0):
+    from exomedepth_amd import synth
+    chrom_off, start, end = synth.exon_design(E, C, seed)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=3, mean_depth=depth)
+    return chrom_off, start, end, test, ref
+
+
+@pytest.mark.parametrize("B", [2, 3, 5])
+def test_fit_bins_matches_checker(edlib, oracle, B):
+    from oracle import bins_oracle as bo
+    E, S = 5000, 6
+    chrom_off, start, end, test, ref = _case(E, S, 3, 70 + B)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dphib = edlib.DeviceArray(np.zeros((B, S)))
+    dedges = edlib.DeviceArray(np.zeros((B + 1, S)))
+    dexp = edlib.DeviceArray(np.zeros(S))
+    batch.fit_bins(test, ref, B, dphib, dedges, dexp)
+    phib, edges, exp = dphib.to_host(), dedges.to_host(), dexp.to_host()
+    philin = batch.phi_linear(ref, B, dphib, dedges)
+    batch.close(); plan.close()
+    for s in range(S):
+        ophi, op, olin, ocomplete = bo.fit_bins(test[:, s], ref[:, s], B)
+        assert np.array_equal(bits(edges[:, s]), bits(ocomplete)), (s, edges[:, s], ocomplete)
+        assert np.max(np.abs(phib[:, s] - ophi) / ophi) < FIT_REL_TOL, (s, phib[:, s], ophi)
+        assert abs(exp[s] - op) / op < FIT_REL_TOL
+        # the interpolation itself, fed the device's own estimates: exact
+        mid = (edges[:B, s] + edges[1:B + 1, s]) / 2
+        mine = bo.approx_linear(ref[:, s].astype(np.float64), mid, phib[:, s])
+        assert np.array_equal(bits(philin[:, s]), bits(mine))
+
+
+def test_binning_failure_is_reported(edlib):
+    """a constant reference column puts every exon in the top level: the reference stops with
+    'Binning did not happen properly' (R/class_definition.R:130-133)"""
+    E, S, B = 600, 3, 3
+    chrom_off, start, end, test, ref = _case(E, S, 2, 90)
+    ref[:, 1] = 500
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    d = [edlib.DeviceArray(np.zeros((B, S))), edlib.DeviceArray(np.zeros((B + 1, S))), edlib.DeviceArray(np.zeros(S))]
+    with pytest.raises(edlib.EdError, match="Binning did not happen properly"):
+        batch.fit_bins(test, ref, B, *d)
+    with pytest.raises(edlib.EdError):
+        batch.fit_bins(test, ref, 1, *d)        # phi.bins = 1 is the plain fit
+    batch.close(); plan.close()
+
+
+def test_run_bins_pipeline_parity(edlib, oracle):
+    """fit -> per-exon phi -> emissions -> Viterbi -> calls; the checker, fed the device's phi.linear, must agree
+    bit for bit on the likelihood, the path and the call table."""
+    E, S, C, B = 4000, 5, 4, 4
+    chrom_off, start, end, test, ref = _case(E, S, C, 95, depth=60.0)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dphib = edlib.DeviceArray(np.zeros((B, S)))
+    dedges = edlib.DeviceArray(np.zeros((B + 1, S)))
+    dexp = edlib.DeviceArray(np.zeros(S))
+    batch.fit_bins(test, ref, B, dphib, dedges, dexp)
+    batch.run_bins(test, ref, B, dphib, dedges, dexp)
+    ll, path, calls = batch.loglik(), batch.path(), batch.calls()
+    info = batch.call_info()
+    philin = batch.phi_linear(ref, B, dphib, dedges)
+    exp = dexp.to_host()
+    batch.set_fused(True)
+    with pytest.raises(edlib.EdError):
+        batch.run_bins(test, ref, B, dphib, dedges, dexp)
+    batch.close(); plan.close()
+    assert len(info) == len(calls)
+    k = 0
+    for s in range(S):
+        exp_ll, _ = oracle.get_loglike_matrix(philin[:, s], np.full(E, exp[s]), test[:, s] + ref[:, s], test[:, s], 1.0,
+                                              oracle.PORTABLE)
+        assert np.array_equal(bits(ll[:, :, s]), bits(exp_ll)), "sample %d" % s
+        # the .Call-shaped entry with the same per-exon phi gives the same bits
+        mine = np.array(edlib.get_loglike_matrix(philin[:, s], np.full(E, exp[s]), test[:, s] + ref[:, s], test[:, s]))
+        assert np.array_equal(bits(mine), bits(exp_ll))
+        exp_path, exp_calls = oracle.callcnvs(exp_ll, chrom_off, start, end)
+        assert np.array_equal(path[:, s].astype(np.int8), exp_path)
+        m = calls[calls["sample"] == s]
+        assert len(m) == len(exp_calls)
+        assert np.array_equal(m["start_exon"] + 1, exp_calls[:, 0].astype(np.int64))
+        assert np.array_equal(m["end_exon"] + 1, exp_calls[:, 1].astype(np.int64))
+        assert np.array_equal(m["type"], exp_calls[:, 2].astype(np.int64))
+        k += len(m)
+    assert k == len(calls) and k > 0
+
+
+def test_mirror_phi_bins(edlib, oracle):
+    """ExomeDepth(..., phi_bins = B).CallCNVs(...) -- the per-sample mirror of the S4 flow with variable phi."""
+    from oracle import bins_oracle as bo
+    E, C, B = 3000, 3, 3
+    chrom_off, start, end, test, ref = _case(E, 2, C, 97)
+    t, r = test[:, 0].astype(float), ref[:, 0].astype(float)
+    x = edlib.ExomeDepth(t, r, phi_bins=B)
+    ophi, op, olin, _ = bo.fit_bins(test[:, 0], ref[:, 0], B)
+    assert x.phi.shape == (E,) and np.max(np.abs(x.phi - olin) / olin) < FIT_REL_TOL
+    assert abs(x.expected[0] - op) / op < FIT_REL_TOL
+    chrom = np.concatenate([[str(c + 1)] * int(chrom_off[c + 1] - chrom_off[c]) for c in range(C)])
+    x.CallCNVs(chrom, start, end, np.array(["e%d" % i for i in range(E)]))
+    exp_ll, _ = oracle.get_loglike_matrix(x.phi, x.expected, test[:, 0] + ref[:, 0], test[:, 0], 1.0, oracle.PORTABLE)
+    assert np.array_equal(bits(x.likelihood), bits(exp_ll))
+    exp_path, exp_calls = oracle.callcnvs(exp_ll, chrom_off, start, end)
+    assert np.array_equal(x.Viterbi_path.astype(np.int8), exp_path)
+    assert [c["start.p"] for c in x.CNV_calls] == list(exp_calls[:, 0].astype(int))
+    assert [c["end.p"] for c in x.CNV_calls] == list(exp_calls[:, 1].astype(int))
+    with pytest.raises(ValueError):
+        edlib.ExomeDepth(t, r, phi_bins=B, subset_for_speed=100)
