@@ -498,12 +498,14 @@ REFSET_DTYPE = np.dtype([("ref_index", "<i4"), ("selected", "<i4"), ("correlatio
 assert REFSET_DTYPE.itemsize == C.sizeof(EdRefsetRow)
 
 
-def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_reduced=0, names=None):
+def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_reduced=0, names=None, prefix_window=None):
     """reference R/optimize_reference_set.R:53-148 (formula ~ 1, phi.bins = 1).
 
     test_counts: (E,) ; reference_counts: (E, R) matrix, one column per candidate reference sample (host array,
     or a torch CUDA int32 tensor of shape (E, R)).  Returns {'reference.choice': [...], 'summary.stats':
-    structured array (REFSET_DTYPE, sorted by decreasing correlation), 'n.bins': int}."""
+    structured array (REFSET_DTYPE, sorted by decreasing correlation), 'n.bins': int}.
+    prefix_window=(begin, end): raw statistics of those cumulative references only (a rank's share, see
+    dist.select_reference_set_sharded); 'reference.choice' is then None until refset_finalize()."""
     keep = []
     if hasattr(reference_counts, "shape") and len(reference_counts.shape) != 2:
         raise ValueError("The reference sequence count data must be provided as a matrix")
@@ -526,12 +528,28 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
     rows = np.zeros(R, dtype=REFSET_DTYPE)
     n_chosen = C.c_int32(0)
     n_sel = C.c_int64(0)
+    if prefix_window is not None:
+        check(lib().ed_select_reference_set_part(pt, pr, E, R, _ptr(bl) if bl is not None else None, int(n_bins_reduced),
+                                                 int(prefix_window[0]), int(prefix_window[1]), _ptr(rows),
+                                                 C.byref(n_chosen), C.byref(n_sel), None))
+        return {"reference.choice": None, "summary.stats": rows, "n.bins": int(n_sel.value),
+                "low.coverage": n_chosen.value == 1}
     check(lib().ed_select_reference_set(pt, pr, E, R, _ptr(bl) if bl is not None else None, int(n_bins_reduced),
                                         _ptr(rows), C.byref(n_chosen), C.byref(n_sel), None))
     if names is None:
         names = ["X%d" % (i + 1) for i in range(R)]       # R/optimize_reference_set.R:76
     choice = [names[int(i)] for i in rows["ref_index"][: n_chosen.value]]
     return {"reference.choice": choice, "summary.stats": rows, "n.bins": int(n_sel.value)}
+
+
+def refset_finalize(rows, names=None):
+    """Early exit + reference.choice (R/optimize_reference_set.R:130, :143-145) on a complete table of raw rows."""
+    rows = np.ascontiguousarray(rows, dtype=REFSET_DTYPE).copy()
+    n_chosen = C.c_int32(0)
+    check(lib().ed_refset_finalize(_ptr(rows), rows.size, C.byref(n_chosen)))
+    if names is None:
+        names = ["X%d" % (i + 1) for i in range(rows.size)]
+    return {"reference.choice": [names[int(i)] for i in rows["ref_index"][: n_chosen.value]], "summary.stats": rows}
 
 
 def _signif(x, digits):

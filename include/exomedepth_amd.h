@@ -222,6 +222,18 @@ int ed_select_reference_set(const int32_t* d_test, const int32_t* d_refs, int64_
                             const double* bin_length, int64_t n_bins_reduced, ed_refset_row* rows, int32_t* n_chosen,
                             int64_t* n_selected_bins, void* stream);
 
+/* The same for the cumulative references prefix_begin <= i < prefix_end of the correlation-sorted axis only (raw
+ * statistics; no early exit, no choice): the prefixes are independent given the order, so N ranks that each hold
+ * the count matrix (4 GB at 500 000 x 2048: replicated, not sharded, in 288 GB of HBM) take contiguous shares and
+ * exchange nothing but these rows.  Every row gets ref_index and correlation; *n_chosen = 0 (1 with
+ * *n_selected_bins = 0 when the coverage is too low, :57-61). */
+int ed_select_reference_set_part(const int32_t* d_test, const int32_t* d_refs, int64_t n_bins, int64_t n_refs,
+                                 const double* bin_length, int64_t n_bins_reduced, int64_t prefix_begin, int64_t prefix_end,
+                                 ed_refset_row* rows, int32_t* n_chosen, int64_t* n_selected_bins, void* stream);
+/* The loop's early exit (:130: statistics up to and including the breaking iteration, expected.BF before it) and
+ * reference.choice (:143-145) on a complete table of raw rows.  Host code only (no device needed). */
+int ed_refset_finalize(ed_refset_row* rows, int64_t n_refs, int32_t* n_chosen);
+
 /* ---- utilities ---- */
 /* device memory through the library, for callers without a HIP binding (tests, R shim) */
 int ed_malloc(void** dptr, size_t bytes);

@@ -58,3 +58,62 @@ def test_gather_call_tables_world_size_2():
         for k in range(s % 3):
             exp.append((s, k % 2, 100 * s + k, 100 * s + k + 4, 1 + (k % 2), 5))
     assert got.tolist() == [list(r) for r in exp]     # ordered by global sample, sample ids shifted per rank
+
+
+def _refset_table(R):
+    """a synthetic table of raw per-prefix rows (what the GPU shares would produce)"""
+    from exomedepth_amd import api
+    rng = np.random.default_rng(11)
+    rows = np.zeros(R, dtype=api.REFSET_DTYPE)
+    rows["ref_index"] = rng.permutation(R)
+    rows["correlation"] = np.sort(rng.uniform(0.9, 0.999, R))[::-1]
+    rows["phi"] = rng.uniform(1e-3, 1e-2, R)
+    rows["mean_p"] = 1.0 / (np.arange(R) + 2.0)            # falls below 0.05 at i = 19: the loop's early exit
+    rows["median_depth"] = 100.0 * (np.arange(R) + 1)
+    rows["ratio_sd"] = rng.uniform(1, 2, R)
+    rows["expected_BF"] = 10 + 5 * np.sin(np.arange(R) / 3.0)
+    return rows
+
+
+def _refset_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exomedepth_amd import api, dist as eddist
+    R = 31
+    full = _refset_table(R)
+
+    def compute_part(lo, hi):     # a rank only knows its own share of the statistics
+        part = np.zeros(R, dtype=api.REFSET_DTYPE)
+        for f in ("phi", "mean_p", "median_depth", "ratio_sd", "expected_BF"):
+            part[f] = np.nan
+            part[f][lo:hi] = full[f][lo:hi]
+        part["ref_index"] = full["ref_index"]
+        part["correlation"] = full["correlation"]
+        return part
+
+    res = eddist.select_reference_set_sharded(None, np.zeros((1, R), dtype=np.int32), compute_part=compute_part)
+    q.put((rank, res["reference.choice"], res["summary.stats"].tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_select_reference_set_sharded_merge_world_size_2():
+    from exomedepth_amd import api
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_refset_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    exp = api.refset_finalize(_refset_table(31))
+    for rank, choice, raw in got:
+        assert choice == exp["reference.choice"]
+        assert raw == exp["summary.stats"].tobytes()         # every rank ends with the same, complete table
+    st = exp["summary.stats"]
+    assert np.isnan(st["expected_BF"][19:]).all() and not np.isnan(st["phi"][19]) and np.isnan(st["phi"][20:]).all()
+    assert len(exp["reference.choice"]) == int(np.nanargmax(st["expected_BF"])) + 1

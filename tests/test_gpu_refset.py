@@ -63,3 +63,29 @@ def test_get_power_betabinom_known_properties(oracle):
     # reference R/tools.R:123-125 examples: positive when the alternative differs, exactly 0 when it does not
     assert ro.get_power_betabinom(200, 0.1, 0.2, 0.6) > 1.0
     assert abs(ro.get_power_betabinom(200, 0.1, 0.2, 0.2)) < 1e-12
+
+
+def test_prefix_shares_merge_to_the_whole(edlib):
+    """The multi-GPU decomposition (dist.select_reference_set_sharded): shares of the sorted prefix axis computed
+    independently, merged and finalised, are the single-GPU result bit for bit -- including a case where the
+    loop's early exit (mean.p < 0.05) falls inside the second share."""
+    for seed, R, scale in ((7, 9, 1.0), (8, 12, 40.0)):
+        test, refs, length = _cohort(5000, R, seed=seed)
+        refs = (refs * scale).astype(np.int32)          # scale 40: the cumulative reference dwarfs the test -> mean.p < 0.05
+        whole = edlib.select_reference_set(test, refs, bin_length=length)
+        cut = R // 2
+        a = edlib.select_reference_set(test, refs, bin_length=length, prefix_window=(0, cut))
+        b = edlib.select_reference_set(test, refs, bin_length=length, prefix_window=(cut, R))
+        assert a["reference.choice"] is None and a["n.bins"] == whole["n.bins"]
+        merged = a["summary.stats"].copy()
+        merged[cut:] = b["summary.stats"][cut:]
+        assert np.array_equal(a["summary.stats"]["ref_index"], b["summary.stats"]["ref_index"])
+        fin = edlib.refset_finalize(merged)
+        w = whole["summary.stats"]
+        for name in w.dtype.names:
+            x, y = fin["summary.stats"][name], w[name]
+            assert np.array_equal(x.view(np.uint8 if x.dtype.itemsize == 1 else ("u4" if x.dtype.itemsize == 4 else "u8")),
+                                  y.view("u4" if y.dtype.itemsize == 4 else "u8")), name
+        assert fin["reference.choice"] == whole["reference.choice"]
+        if scale > 1:
+            assert np.isnan(w["expected_BF"]).any()      # the early exit did trigger
