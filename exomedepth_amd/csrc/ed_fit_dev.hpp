@@ -39,7 +39,7 @@ __device__ __forceinline__ double flog(double x)   // x normal, positive, finite
   const double z = s * s;
   double g = c[ED_PM_LOG_NC - 1];
 #pragma unroll
-  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = __builtin_fma(g, z, c[i]);
+  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma_k(g, z, c[i]);
   const double hfsq = (0.5 * f) * f;
   const double dk = (double)k;
   const double w = __builtin_fma(s, hfsq + z * g, dk * ED_PM_LN2_LO);
@@ -62,22 +62,22 @@ __device__ __forceinline__ void digamma_trigamma_nolog(double x, double& xs, dou
   const double w = r * r;
   // psi(x)  = ln x - 1/(2x) - sum_k B_2k / (2k x^2k)
   double p = 1.0 / 12.0;                       // B14/14
-  p = __builtin_fma(p, w, -691.0 / 32760.0);   // B12/12
-  p = __builtin_fma(p, w, 1.0 / 132.0);        // B10/10
-  p = __builtin_fma(p, w, -1.0 / 240.0);       // B8/8
-  p = __builtin_fma(p, w, 1.0 / 252.0);        // B6/6
-  p = __builtin_fma(p, w, -1.0 / 120.0);       // B4/4
-  p = __builtin_fma(p, w, 1.0 / 12.0);         // B2/2
+  p = ed_pm_fma_k(p, w, -691.0 / 32760.0);   // B12/12
+  p = ed_pm_fma_k(p, w, 1.0 / 132.0);        // B10/10
+  p = ed_pm_fma_k(p, w, -1.0 / 240.0);       // B8/8
+  p = ed_pm_fma_k(p, w, 1.0 / 252.0);        // B6/6
+  p = ed_pm_fma_k(p, w, -1.0 / 120.0);       // B4/4
+  p = ed_pm_fma_k(p, w, 1.0 / 12.0);         // B2/2
   psi_rest = (-0.5 * r - p * w) - s0;          // psi(x_original) = ln(xs) + psi_rest
   xs = x;
   // psi'(x) = 1/x + 1/(2x^2) + sum_k B_2k / x^(2k+1)
   double q = 7.0 / 6.0;                        // B14
-  q = __builtin_fma(q, w, -691.0 / 2730.0);    // B12
-  q = __builtin_fma(q, w, 5.0 / 66.0);         // B10
-  q = __builtin_fma(q, w, -1.0 / 30.0);        // B8
-  q = __builtin_fma(q, w, 1.0 / 42.0);         // B6
-  q = __builtin_fma(q, w, -1.0 / 30.0);        // B4
-  q = __builtin_fma(q, w, 1.0 / 6.0);          // B2
+  q = ed_pm_fma_k(q, w, -691.0 / 2730.0);    // B12
+  q = ed_pm_fma_k(q, w, 5.0 / 66.0);         // B10
+  q = ed_pm_fma_k(q, w, -1.0 / 30.0);        // B8
+  q = ed_pm_fma_k(q, w, 1.0 / 42.0);         // B6
+  q = ed_pm_fma_k(q, w, -1.0 / 30.0);        // B4
+  q = ed_pm_fma_k(q, w, 1.0 / 6.0);          // B2
   psi1 = __builtin_fma(q * w, r, __builtin_fma(0.5, w, r)) + s1;
 }
 

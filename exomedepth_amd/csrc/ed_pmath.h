@@ -49,6 +49,19 @@
 ED_PM_FN uint64_t ed_pm_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 ED_PM_FN double ed_pm_from_bits(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 ED_PM_FN double ed_pm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* fma(a, b, k) with a compile-time constant addend k (Horner steps).  Same operation, same bits; on the device the
+ * constant is handed over in scalar registers: left to itself the compiler picks v_fmac_f64, whose addend must
+ * already sit in the destination VGPRs, and spends two extra vector moves per coefficient to put it there. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ static __inline__ __attribute__((always_inline)) double ed_pm_fma_k(double a, double b, double k)
+{
+  double d;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+  return d;
+}
+#else
+ED_PM_FN double ed_pm_fma_k(double a, double b, double k) { return __builtin_fma(a, b, k); }
+#endif
 ED_PM_FN double ed_pm_inf(void) { return ed_pm_from_bits(0x7ff0000000000000ULL); }
 ED_PM_FN double ed_pm_nan(void) { return ed_pm_from_bits(0x7ff8000000000000ULL); }
 
@@ -76,7 +89,7 @@ ED_PM_FN double ed_plog(double x)
   const double s = f / (2.0 + f);
   const double z = s * s;
   double g = c[ED_PM_LOG_NC - 1];
-  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma(g, z, c[i]);
+  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma_k(g, z, c[i]);
   const double R = z * g;
   const double hfsq = (0.5 * f) * f;
   const double dk = (double)k;
@@ -98,7 +111,7 @@ ED_PM_FN double ed_pexp(double x)
   double r = ed_pm_fma(-kd, ED_PM_LN2_HI, x);           /* exact */
   r = ed_pm_fma(-kd, ED_PM_LN2_LO, r);
   double q = c[ED_PM_EXP_NC - 1];
-  for (int i = ED_PM_EXP_NC - 2; i >= 0; --i) q = ed_pm_fma(q, r, c[i]);
+  for (int i = ED_PM_EXP_NC - 2; i >= 0; --i) q = ed_pm_fma_k(q, r, c[i]);
   const double p = ed_pm_fma(r * r, q, r);
   double e = 1.0 + p;
   const int k = (int)kd;
@@ -122,7 +135,7 @@ ED_PM_FN double ed_psin_0pi(double t)
   if (t > 0.5 * ED_PM_PI_HI) t = (ED_PM_PI_HI - t) + ED_PM_PI_LO;
   const double w = t * t;
   double p = c[ED_PM_SIN_NC - 1];
-  for (int i = ED_PM_SIN_NC - 2; i >= 0; --i) p = ed_pm_fma(p, w, c[i]);
+  for (int i = ED_PM_SIN_NC - 2; i >= 0; --i) p = ed_pm_fma_k(p, w, c[i]);
   return ed_pm_fma(t * w, p, t);
 }
 

@@ -88,7 +88,7 @@ __device__ __forceinline__ double pexp_small(double x)
   const double c[ED_PM_EXP_NC] = ED_PM_EXP_COEFFS;
   double q = c[ED_PM_EXP_NC - 1];
 #pragma unroll
-  for (int i = ED_PM_EXP_NC - 2; i >= 0; --i) q = ed_pm_fma(q, x, c[i]);
+  for (int i = ED_PM_EXP_NC - 2; i >= 0; --i) q = ed_pm_fma_k(q, x, c[i]);
   return 1.0 + ed_pm_fma(x * x, q, x);
 }
 
@@ -105,7 +105,7 @@ __device__ __forceinline__ double plog_pos(double x)
   const double z = s * s;
   double g = c[ED_PM_LOG_NC - 1];
 #pragma unroll
-  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma(g, z, c[i]);
+  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma_k(g, z, c[i]);
   const double R = z * g;
   const double hfsq = (0.5 * f) * f;
   const double dk = (double)k;

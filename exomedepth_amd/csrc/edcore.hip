@@ -120,12 +120,13 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
 // one exon (coalesced) and writes three coalesced rows of the [E][3][S] likelihood matrix.
 constexpr int kEmitCells = 2;                                // cells per thread
 constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per workgroup
+constexpr int kEmitRows = kEmitCells * kEmitBlock / 64;      // exons per workgroup tile (x 64 samples)
 constexpr int64_t kEmitHeadBlocks = 2048;                    // workgroups of a group's short leading launch (ed_batch_run)
 
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
              const int* __restrict__ cflags, const int64_t* __restrict__ seg, int nseg, int64_t blk_base, int64_t S,
-             double* __restrict__ loglik, unsigned long long* __restrict__ nerr)
+             uint32_t nsb, double* __restrict__ loglik, unsigned long long* __restrict__ nerr)
 {
   __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
   __shared__ double t_b[kEmitTasks];   // max (ratio route) or y
@@ -135,27 +136,31 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   const int lane = tid & 63;
   if (tid == 0) { n_front = 0; n_back = 0; }
   __syncthreads();
-  // The batch's cells are cut into nseg segments of whole chromosomes (job order); seg[3*i .. 3*i+2] = (first
-  // workgroup, first cell, end cell) of segment i.  This launch covers workgroups blk_base .. blk_base+gridDim.x-1
-  // of that numbering; a short uniform search finds the workgroup's segment.
+  // The batch's exons are cut into nseg segments of whole chromosomes (job order); seg[3*i .. 3*i+2] = (first
+  // workgroup, first exon, end exon) of segment i.  A workgroup owns a tile of kEmitRows exons x 64 samples (a wave
+  // reads 64 consecutive samples of one exon; no per-cell division); inside a segment the workgroups are numbered
+  // exon-block major over nsb = ceil(S / 64) sample blocks.  This launch covers workgroups blk_base ..
+  // blk_base + gridDim.x - 1 of that numbering; a short uniform search finds the workgroup's segment.
   const int64_t blk = (int64_t)blockIdx.x + blk_base;
   int si = 0;
   while (si + 1 < nseg && seg[3 * (si + 1)] <= blk) ++si;
-  const int64_t ncell = seg[3 * si + 2];
-  const int64_t cell0 = seg[3 * si + 1] + (blk - seg[3 * si]) * (kEmitBlock * kEmitCells) + tid;
+  const uint32_t local = (uint32_t)(blk - seg[3 * si]);
+  const uint32_t eb = local / nsb, sb = local - eb * nsb;
+  const int64_t e_end = seg[3 * si + 2];
+  const int64_t e_first = seg[3 * si + 1] + (int64_t)eb * kEmitRows + (tid >> 6);
+  const int64_t s = (int64_t)sb * 64 + lane;
   int slot[kEmitCells * 3];
   int nflag = 0;
   // ---- phase 1: classify and scatter the tasks ----
 #pragma unroll
   for (int k = 0; k < kEmitCells; ++k) {
-    const int64_t cell = cell0 + (int64_t)k * kEmitBlock;
-    const bool live = cell < ncell;
+    const int64_t e = e_first + (int64_t)k * (kEmitBlock / 64);
+    const bool live = (e < e_end) && (s < S);
     int32_t obs = 0, tot = 0;
-    int64_t s = 0;
     if (live) {
+      const int64_t cell = e * S + s;
       obs = test[cell];
       tot = obs + ref[cell];   // as.integer(reference + test), R/class_definition.R:187
-      s = cell % S;
     }
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
@@ -213,10 +218,8 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   // ---- phase 3: gather, subtract the per-sample constant, store ----
 #pragma unroll
   for (int k = 0; k < kEmitCells; ++k) {
-    const int64_t cell = cell0 + (int64_t)k * kEmitBlock;
-    if (cell < ncell) {
-      const int64_t e = cell / S;
-      const int64_t s = cell - e * S;
+    const int64_t e = e_first + (int64_t)k * (kEmitBlock / 64);
+    if ((e < e_end) && (s < S)) {
 #pragma unroll
       for (int st = 0; st < 3; ++st) {
         const double c = consts[(st * 3 + 2) * S + s];
@@ -1131,7 +1134,7 @@ struct ed_batch {
   uint8_t* d_last = nullptr;     // [C][S] state of each chain's last exon (end of the forward pass)
   int32_t* d_job_off = nullptr;  // [n_jobs + 1]
   int32_t* d_job_chrom = nullptr;  // chromosomes in job order
-  int64_t* d_seg = nullptr;        // emission segments in job order: (first workgroup, first cell, end cell) x n_jobs
+  int64_t* d_seg = nullptr;        // emission segments in job order: (first workgroup, first exon, end exon) x n_jobs
   std::vector<int64_t> seg;        // host copy (+ one closing entry holding the total workgroup count)
   int32_t n_jobs = 0;
   std::vector<std::vector<int>> jobs;   // host copy: chromosomes of each Viterbi job
@@ -1526,9 +1529,9 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     int64_t blk = 0;
     for (auto& jb : jobs) {
       const int c = jb[0];
-      const int64_t cb = (int64_t)plan->chrom_off[c] * S, ce = (int64_t)plan->chrom_off[c + 1] * S;
-      b->seg.push_back(blk); b->seg.push_back(cb); b->seg.push_back(ce);
-      blk += (ce - cb + kEmitBlock * kEmitCells - 1) / (kEmitBlock * kEmitCells);
+      const int64_t eb = plan->chrom_off[c], ee = plan->chrom_off[c + 1];
+      b->seg.push_back(blk); b->seg.push_back(eb); b->seg.push_back(ee);
+      blk += ((ee - eb + kEmitRows - 1) / kEmitRows) * ((S + 63) / 64);
     }
     b->seg.push_back(blk); b->seg.push_back(0); b->seg.push_back(0);
     HIP_TRY(hipMalloc((void**)&b->d_seg, b->seg.size() * 8));
@@ -1622,10 +1625,10 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
                            d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S, b->d_loglik, b->d_nerr);
       if (head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
-                           b->d_seg, b->n_jobs, blk0, S, b->d_loglik, b->d_nerr);
+                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_loglik, b->d_nerr);
       if (nblk - head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
-                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, b->d_loglik, b->d_nerr);
+                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, (uint32_t)((S + 63) / 64), b->d_loglik, b->d_nerr);
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
       HIP_TRY(hipStreamWaitEvent(b->side, b->job_ev[g], 0));
       const dim3 gw((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)(j1 - j0));
@@ -1678,6 +1681,8 @@ struct FitWork {
     S = S_;
     nchunk = ((E + kFitChunk - 1) / kFitChunk) * kFitSub;
     HIP_TRY(hipMalloc((void**)&partial, (size_t)std::max<int64_t>(nchunk, 1) * kFitQ * S * 8));
+    // all-ones = NaN: a chunk read without having been written by the current fit shows up instead of passing as zero
+    HIP_TRY(hipMemset(partial, 0xff, (size_t)std::max<int64_t>(nchunk, 1) * kFitQ * S * 8));
     HIP_TRY(hipMalloc((void**)&eta, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&lam, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&done, (size_t)S * 4));
@@ -1701,21 +1706,22 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
                        int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st)
 {
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
+  const int64_t nch = nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
   const dim3 grid((unsigned)((S + kWave - 1) / kWave), (unsigned)nblk), block(kWave, kFitSub);
   const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
   hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 4, w.partial);
-  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done);
+  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done);
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
   const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   for (int it = 0; it < coarse; ++it) {
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 16, w.eta, w.lam, w.done, w.partial);
-    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done, 1e-6, 0);
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 0);
   }
   for (int it = 0; it < 10; ++it) {   // converged columns skip their work; typically 3 passes do something
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 1, w.eta, w.lam, w.done, w.partial);
-    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, w.nchunk, S, w.eta, w.lam, w.done, 1e-6, 1);
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 1);
   }
   hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
   HIP_TRY(hipGetLastError());
