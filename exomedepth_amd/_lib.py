@@ -49,6 +49,7 @@ SYMBOLS = [
     ("ed_batch_create", C.c_int, [C.POINTER(_vp), _vp, _i64]),
     ("ed_batch_destroy", None, [_vp]),
     ("ed_batch_fit", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ed_batch_set_fit_histograms", C.c_int, [_vp, C.c_int]),
     ("ed_batch_fit_subset", C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     ("ed_batch_fit_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     ("ed_batch_run_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),

@@ -223,6 +223,10 @@ class Batch:
         """Keep (default) or drop the (n_exons, 3, n_samples) likelihood matrix -- 24 bytes per cell of HBM."""
         check(lib().ed_batch_keep_loglik(self.handle, 1 if keep else 0))
 
+    def set_fit_histograms(self, on=True):
+        """fit(): iterate on per-sample count histograms (default) or per cell on every pass."""
+        check(lib().ed_batch_set_fit_histograms(self.handle, 1 if on else 0))
+
     @property
     def n_emit_launches(self):
         """emission-kernel launches per run (overlap groups; 1 in fused mode)"""

@@ -986,23 +986,16 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
   o[0] = acc.ga; o[S] = acc.gb; o[2 * S] = acc.haa; o[3 * S] = acc.hab; o[4 * S] = acc.hbb; o[5 * S] = cnt;
 }
 
-// One Newton step on (eta, lambda) = (logit p, log(a+b)); steps are capped, and a non-concave local
-// model falls back to a scaled gradient step.  `final_pass` marks passes over all exons: only those
-// may declare convergence.
-__global__ void __launch_bounds__(kWave * kRedY)
-k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
-             double* __restrict__ lam, int* __restrict__ done, double tol, int final_pass)
+// One Newton step on (eta, lambda) = (logit p, log(a+b)) from the summed gradient/Hessian of the log-likelihood
+// with respect to (a, b) (tot = ga, gb, haa, hab, hbb, #cells, without the per-sample constant terms).  Steps are
+// capped, and a non-concave local model falls back to a scaled gradient step.  `final_pass` marks passes over
+// all exons: only those may declare convergence.
+__device__ __forceinline__ void fit_newton_step(const double (&tot)[kFitQ], double& eta_v, double& lam_v, int& done_v, double tol,
+                                                int final_pass)
 {
-  __shared__ double lds[kFitQ][kRedY][kWave];
-  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  const bool live = (s < S) && !done[s < S ? s : 0];
-  if (!__syncthreads_or(live ? 1 : 0)) return;   // the whole tile has converged
-  double tot[kFitQ];
-  reduce_partials(partial, nchunk, S, s, live, tot, lds);
-  if (!live || threadIdx.y != 0) return;
   double ga = tot[0], gb = tot[1], haa = tot[2], hab = tot[3], hbb = tot[4], cnt = tot[5];
-  const double th = ed_pexp(lam[s]);
-  const double p = 1.0 / (1.0 + ed_pexp(-eta[s]));
+  const double th = ed_pexp(lam_v);
+  const double p = 1.0 / (1.0 + ed_pexp(-eta_v));
   const double q = 1.0 - p;
   const double a = th * p, b = th * q;
   double pa, qa, pb, qb, pt, qt;
@@ -1058,14 +1051,229 @@ k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, doub
   // phi in [1e-6, 2/3].  Below phi ~ 1e-6 the model is numerically binomial: a + b > 1e6 and the digamma
   // differences that make up the gradient cancel to noise, so the dispersion is not estimable in binary64.
   npsi = fmin(fmax(npsi, 1e-6), 2.0);
-  const double ne = fmin(fmax(eta[s] + de, -20.0), 20.0);
-  eta[s] = ne;
-  lam[s] = -ed_plog(npsi);
+  const double ne = fmin(fmax(eta_v + de, -20.0), 20.0);
+  eta_v = ne;
+  lam_v = -ed_plog(npsi);
   // Newton converges quadratically: once a step over ALL exons is below tol (1e-6, relative for psi), the
   // error left after applying it is of order tol^2, far below the 1e-8 the fit is held to -- no
   // confirming pass is needed.  A sample pinned at the lower bound of psi has also converged.
   const bool at_floor = (npsi <= 1e-6 && psi <= 1.0000001e-6);
-  if (final_pass && ((fabs(de) < tol && fabs(npsi - psi) < tol * psi) || at_floor)) done[s] = 1;
+  if (final_pass && ((fabs(de) < tol && fabs(npsi - psi) < tol * psi) || at_floor)) done_v = 1;
+}
+
+__global__ void __launch_bounds__(kWave * kRedY)
+k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
+             double* __restrict__ lam, int* __restrict__ done, double tol, int final_pass)
+{
+  __shared__ double lds[kFitQ][kRedY][kWave];
+  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const bool live = (s < S) && !done[s < S ? s : 0];
+  if (!__syncthreads_or(live ? 1 : 0)) return;   // the whole tile has converged
+  double tot[kFitQ];
+  reduce_partials(partial, nchunk, S, s, live, tot, lds);
+  if (!live || threadIdx.y != 0) return;
+  double e = eta[s], l = lam[s];
+  int d = 0;
+  fit_newton_step(tot, e, l, d, tol, final_pass);
+  eta[s] = e; lam[s] = l;
+  if (d) done[s] = 1;
+}
+
+// ---- K5 through count histograms --------------------------------------------------------------------
+// The gradient and Hessian of the log-likelihood are sums over cells of psi / psi' at a + y, b + (n - y) and
+// a + b + n: functions of ONE count each.  So they are sums over the distinct values of y, n - y and n weighted by
+// how often each value occurs in the sample -- three histograms per sample, built in ONE pass over the counts
+// (k_fit_hist: LDS-privatised, 4 samples per workgroup).  Every Newton iteration then costs ~9 000 digamma
+// evaluations per sample instead of 3 x n_exons, and all iterations run inside one launch (k_fit_hnewton).  Cells
+// with a count beyond the histogram range go to a per-sample overflow list and are evaluated one by one; a
+// sample whose list overflows, or that has not converged, is finished by the per-cell kernels above.
+// (Sums are grouped by value instead of by exon: the result differs from the per-cell path by rounding only.)
+constexpr int kHistKy = 1024;                            // bins of the test count
+constexpr int kHistKr = 4096;                            // bins of the reference count
+constexpr int kHistKn = 4096;                            // bins of the total
+constexpr int kHistK = kHistKy + kHistKr + kHistKn;
+constexpr int kHistSamples = 4;                          // samples per workgroup: 4 x 9216 x 4 B = 147 456 B of LDS
+constexpr int kHistBlock = 1024;
+
+__global__ void __launch_bounds__(kHistBlock)
+k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t rs, int64_t E, int64_t S,
+           uint32_t* __restrict__ hist, int32_t* __restrict__ ov_y, int32_t* __restrict__ ov_r, int32_t* __restrict__ ovn,
+           int64_t cap)   // cap: overflow cells per (row group, sample); row group t = tid / 4 owns rows t, t + 256, ...
+{
+  __shared__ uint32_t hsm[kHistSamples * kHistK];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kHistSamples * kHistK; i += kHistBlock) hsm[i] = 0;
+  __syncthreads();
+  // Workgroups are dealt to the 8 XCDs round-robin, and 8 neighbouring sample quads share every 128-byte line of
+  // a count row: neighbours must sit on the SAME XCD (one L2) or each line is fetched up to 8 times.  So XCD x
+  // (= blockIdx % 8) owns the contiguous quads [x * per, (x + 1) * per).
+  const int64_t nq = (S + kHistSamples - 1) / kHistSamples, per = (nq + 7) / 8;
+  const int64_t quad = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int j = tid & (kHistSamples - 1);
+  const int64_t s = (quad < nq && (int64_t)(blockIdx.x >> 3) < per) ? quad * kHistSamples + j : S;
+  uint32_t* __restrict__ h = hsm + j * kHistK;
+  int nov = 0;   // this thread's overflow cells: stored in row order in its own region -- no atomics, and the
+                 // order in which k_fit_hnewton adds them up is the same on every run
+  constexpr int kRows = kHistBlock / kHistSamples;   // rows per sweep of the workgroup = row groups
+  const int64_t ovbase = (int64_t)(tid / kHistSamples) * cap;
+  if (s < S) {
+    constexpr int kPre = 4;                              // rows in flight per thread
+    int yb[kPre], rb[kPre];
+    const int64_t e0 = tid / kHistSamples;
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int64_t e = e0 + (int64_t)k * kRows;
+      yb[k] = (e < E) ? test[e * rs + s] : 0;
+      rb[k] = (e < E) ? ref[e * rs + s] : 0;
+    }
+    for (int64_t e = e0; e < E; e += (int64_t)kPre * kRows) {
+      int yc[kPre], rc[kPre];
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) { yc[k] = yb[k]; rc[k] = rb[k]; }
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        const int64_t en = e + (int64_t)(kPre + k) * kRows;
+        yb[k] = (en < E) ? test[en * rs + s] : 0;
+        rb[k] = (en < E) ? ref[en * rs + s] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        if (e + (int64_t)k * kRows >= E) break;
+        const int y = yc[k], r = rc[k];
+        const int n = y + r;
+        if (n <= 0) continue;   // carries no information (and is not counted), as in accumulate_cell
+        if ((unsigned)y < (unsigned)kHistKy && (unsigned)r < (unsigned)kHistKr && (unsigned)n < (unsigned)kHistKn) {
+          atomicAdd(&h[y], 1u);
+          atomicAdd(&h[kHistKy + r], 1u);
+          atomicAdd(&h[kHistKy + kHistKr + n], 1u);
+        } else {
+          if (nov < cap) { ov_y[(ovbase + nov) * S + s] = y; ov_r[(ovbase + nov) * S + s] = r; }
+          ++nov;
+        }
+      }
+    }
+  }
+  if (s < S) ovn[(int64_t)(tid / kHistSamples) * S + s] = nov;
+  __syncthreads();
+  for (int i = tid; i < kHistSamples * kHistK; i += kHistBlock) {
+    const int v = i / kHistSamples, jj = i % kHistSamples;
+    const int64_t ss = quad * kHistSamples + jj;
+    if (quad < nq && ss < S) hist[(int64_t)v * S + ss] = hsm[jj * kHistK + v];
+  }
+}
+
+// All Newton iterations of 4 samples in one launch: 256 strands per sample share the bins and the overflow
+// regions (strand y: bins y, y + 256, ...; row group y), a fixed-order LDS tree adds them up,
+// strand 0 takes the step.
+constexpr int kHnS = 4;    // samples per workgroup
+constexpr int kHnY = 256;  // strands per sample
+constexpr int kHistGroups = kHistBlock / kHistSamples;   // overflow regions per sample (row groups of k_fit_hist)
+static_assert(kHistGroups % kHnY == 0, "every strand owns whole overflow regions");
+
+__global__ void __launch_bounds__(kHnS * kHnY)
+k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_y, const int32_t* __restrict__ ov_r,
+              const int32_t* __restrict__ ovn, int64_t cap, int64_t S, double* __restrict__ eta, double* __restrict__ lam,
+              int* __restrict__ done, int max_iter, double tol)
+{
+  __shared__ double lds[kFitQ][kHnY][kHnS];
+  __shared__ double sh_eta[kHnS], sh_lam[kHnS];
+  __shared__ int sh_done[kHnS], sh_over[kHnS];
+  const int lane = threadIdx.x, y = threadIdx.y;
+  const int64_t s = (int64_t)blockIdx.x * kHnS + lane;
+  const bool live = s < S;
+  const int64_t sc = live ? s : S - 1;
+  if (y == 0) sh_over[lane] = 0;
+  __syncthreads();
+  int cnt[kHistGroups / kHnY];
+  bool over = false;
+#pragma unroll
+  for (int k = 0; k < kHistGroups / kHnY; ++k) {
+    cnt[k] = ovn[(int64_t)(y + k * kHnY) * S + sc];
+    over |= cnt[k] > cap;
+  }
+  if (over) atomicOr(&sh_over[lane], 1);
+  __syncthreads();
+  const bool fits = !sh_over[lane];            // otherwise the per-cell kernels take this sample
+  if (y == 0) {
+    sh_eta[lane] = eta[sc];
+    sh_lam[lane] = lam[sc];
+    sh_done[lane] = (live && fits) ? done[sc] : 1;
+  }
+  __syncthreads();
+  for (int it = 0; it < max_iter; ++it) {
+    const int dn = sh_done[lane];
+    if (__syncthreads_and(dn)) break;
+    double acc[kFitQ];
+#pragma unroll
+    for (int q = 0; q < kFitQ; ++q) acc[q] = 0.0;
+    if (!dn) {
+      const double th = ed_pexp(sh_lam[lane]);
+      const double p = 1.0 / (1.0 + ed_pexp(-sh_eta[lane]));
+      const double a = th * p, b = th * (1.0 - p);
+      for (int v = y; v < kHistKy; v += kHnY) {
+        const uint32_t c = hist[(int64_t)v * S + sc];
+        if (c) {
+          double ps, p1;
+          edfit::digamma_trigamma(a + (double)v, ps, p1);
+          acc[0] += (double)c * ps; acc[2] += (double)c * p1;
+        }
+      }
+      for (int v = y; v < kHistKr; v += kHnY) {
+        const uint32_t c = hist[(int64_t)(kHistKy + v) * S + sc];
+        if (c) {
+          double ps, p1;
+          edfit::digamma_trigamma(b + (double)v, ps, p1);
+          acc[1] += (double)c * ps; acc[4] += (double)c * p1;
+        }
+      }
+      for (int v = y; v < kHistKn; v += kHnY) {
+        const uint32_t c = hist[(int64_t)(kHistKy + kHistKr + v) * S + sc];
+        if (c) {
+          double ps, p1;
+          edfit::digamma_trigamma(th + (double)v, ps, p1);
+          const double cd = (double)c;
+          acc[0] -= cd * ps; acc[1] -= cd * ps;
+          acc[2] -= cd * p1; acc[3] -= cd * p1; acc[4] -= cd * p1;
+          acc[5] += cd;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kHistGroups / kHnY; ++k) {
+        const int64_t base = (int64_t)(y + k * kHnY) * cap;
+        for (int i = 0; i < cnt[k]; ++i) {
+          const int yy = ov_y[(base + i) * S + sc], rr = ov_r[(base + i) * S + sc];
+          edfit::Acc c = {0, 0, 0, 0, 0};
+          edfit::accumulate_cell(c, a, b, th, yy, yy + rr);
+          acc[0] += c.ga; acc[1] += c.gb; acc[2] += c.haa; acc[3] += c.hab; acc[4] += c.hbb; acc[5] += 1.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kFitQ; ++q) lds[q][y][lane] = acc[q];
+    __syncthreads();
+    for (int hh = kHnY / 2; hh >= 1; hh >>= 1) {
+      if (y < hh) {
+#pragma unroll
+        for (int q = 0; q < kFitQ; ++q) lds[q][y][lane] += lds[q][y + hh][lane];
+      }
+      __syncthreads();
+    }
+    if (y == 0 && !dn) {
+      double tot[kFitQ];
+#pragma unroll
+      for (int q = 0; q < kFitQ; ++q) tot[q] = lds[q][0][lane];
+      double e = sh_eta[lane], l = sh_lam[lane];
+      int d = 0;
+      fit_newton_step(tot, e, l, d, tol, 1);
+      sh_eta[lane] = e; sh_lam[lane] = l; sh_done[lane] = d;
+    }
+    __syncthreads();
+  }
+  if (y == 0 && live && fits) {
+    eta[s] = sh_eta[lane];
+    lam[s] = sh_lam[lane];
+    done[s] = sh_done[lane];
+  }
 }
 
 __global__ void k_fit_finish(const double* __restrict__ eta, const double* __restrict__ lam, int64_t S,
@@ -1158,6 +1366,7 @@ struct ed_batch {
   bool ran = false;
   bool fused = false;        // run emissions + Viterbi as ONE kernel (edfused.inc) instead of two overlapped ones
   bool keep_loglik = true;   // fused mode only: also write the [E][3][S] likelihood matrix (the S4 `likelihood` slot)
+  bool fit_hist = true;      // ed_batch_fit: iterate on count histograms (one pass over the counts) instead of per cell
   bool timing = false;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_run_times = false, have_fit_time = false;
@@ -1674,11 +1883,28 @@ struct FitWork {
   double* eta = nullptr;
   double* lam = nullptr;
   int* done = nullptr;
-  int64_t nchunk = 0, S = 0;
+  uint32_t* hist = nullptr;    // [kHistK][S] count histograms (k_fit_hist)
+  int32_t* ov_y = nullptr;     // [kHistGroups][ov_cap][S] cells beyond the histogram range, per row group of k_fit_hist
+  int32_t* ov_r = nullptr;
+  int32_t* ovn = nullptr;      // [kHistGroups][S] overflow cells of each (row group, sample)
+  int64_t ov_cap = 0;
+  int64_t nchunk = 0, S = 0, E_max = 0;
+  int alloc_hist()
+  {
+    if (hist) return ED_OK;
+    const int64_t E = E_max;   // sized for the largest fit this workspace serves
+    ov_cap = std::max<int64_t>(8, (E / kHistGroups) / 8 + 1);   // per (row group, sample): ~1/8 of the group's rows
+    HIP_TRY(hipMalloc((void**)&hist, (size_t)kHistK * S * 4));
+    HIP_TRY(hipMalloc((void**)&ov_y, (size_t)ov_cap * kHistGroups * S * 4));
+    HIP_TRY(hipMalloc((void**)&ov_r, (size_t)ov_cap * kHistGroups * S * 4));
+    HIP_TRY(hipMalloc((void**)&ovn, (size_t)kHistGroups * S * 4));
+    return ED_OK;
+  }
   int alloc(int64_t E, int64_t S_)
   {
     release();
     S = S_;
+    E_max = E;
     nchunk = ((E + kFitChunk - 1) / kFitChunk) * kFitSub;
     HIP_TRY(hipMalloc((void**)&partial, (size_t)std::max<int64_t>(nchunk, 1) * kFitQ * S * 8));
     // all-ones = NaN: a chunk read without having been written by the current fit shows up instead of passing as zero
@@ -1690,9 +1916,9 @@ struct FitWork {
   }
   void release()
   {
-    void* ptrs[] = {partial, eta, lam, done};
+    void* ptrs[] = {partial, eta, lam, done, hist, ov_y, ov_r, ovn};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    partial = eta = lam = nullptr; done = nullptr;
+    partial = eta = lam = nullptr; done = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr;
   }
 };
 
@@ -1702,8 +1928,10 @@ static void fitwork_free(FitWork* w)
 }
 
 // Fit S columns: column s has test counts test[e*trs + s*tcs] and reference counts ref[e*rrs + s], e < E.
+// use_hist: build count histograms once and iterate on them (needs one test column per sample laid out like the
+// reference counts: tcs == 1, trs == rrs); the per-cell passes that follow then only serve samples it left over.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
-                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st)
+                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, bool use_hist = false)
 {
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
   const int64_t nch = nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
@@ -1713,8 +1941,16 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
   hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 4, w.partial);
   hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done);
+  if (use_hist) {
+    if (tcs != 1 || trs != rrs) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
+    if (int rc = w.alloc_hist()) return rc;
+    hipLaunchKernelGGL(k_fit_hist, dim3((unsigned)(((((S + kHistSamples - 1) / kHistSamples) + 7) / 8) * 8)), dim3(kHistBlock), 0, st, d_test, d_ref,
+                       rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap);
+    hipLaunchKernelGGL(k_fit_hnewton, dim3((unsigned)((S + kHnS - 1) / kHnS)), dim3(kHnS, kHnY), 0, st, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap, S,
+                       w.eta, w.lam, w.done, 40, 1e-6);
+  }
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
-  const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
+  const int coarse = (E >= 8192 && !use_hist) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   for (int it = 0; it < coarse; ++it) {
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 16, w.eta, w.lam, w.done, w.partial);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 0);
@@ -1746,7 +1982,7 @@ ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int3
   b->stream = st;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
   const int64_t rows = (E - 1) / by + 1;
-  if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st)) return rc;
+  if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist)) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[6], st));
   b->have_fit_time = b->timing;
   return ED_OK;
@@ -1764,6 +2000,13 @@ ED_EXPORT int ed_batch_set_fused(ed_batch* b, int fused)
 {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->fused = fused != 0;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_set_fit_histograms(ed_batch* b, int on)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  b->fit_hist = on != 0;
   return ED_OK;
 }
 

@@ -126,6 +126,10 @@ void ed_batch_destroy(ed_batch* batch);
  * d_test/d_ref: int32 [n_exons][n_samples] sample-minor DEVICE matrices. */
 int ed_batch_fit(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
                  void* stream);
+/* How ed_batch_fit iterates: 1 (default) on per-sample count histograms built in one pass over the counts
+ * (every Newton iteration then costs ~9 000 digamma evaluations per sample instead of 3 x n_exons); 0 per cell on
+ * every pass.  Same maximum; the two differ by summation order only. */
+int ed_batch_set_fit_histograms(ed_batch* batch, int on);
 /* The same fit on every `by`-th exon only (exons 0, by, 2*by, ...): the scalar form of subset.for.speed,
  * reference R/class_definition.R:107-113, where by = floor(n_exons / subset.for.speed).  by = 1 is ed_batch_fit. */
 int ed_batch_fit_subset(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, int64_t by, double* d_phi,
