@@ -43,7 +43,7 @@ def pmc_traffic(kernel, n_launch):
     return per_step / n_launch, os.path.basename(files[-1])
 
 
-def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit):
+def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit, allcores=False, test_all=None, p_all=None, phi_all=None):
     """The CPU checker's libm flavour (bit-identical to the reference's compiled special functions)
     timed on one host core over a bounded sample of the same workload."""
     from oracle import edoracle as eo
@@ -69,7 +69,16 @@ def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit):
         for s in range(n_fit):
             eo.fit_nm(test_h[:, s], ref_h[:, s])
         t_fit = (time.perf_counter() - t0) * (n_s / n_fit)   # extrapolated linearly to the n_s samples
-    return {"value": cells / (t_emit + t_vit + t_fit), "unit": "exons*samples/s", "cores": 1, "kind": "port",
+    extra = {}
+    if allcores:
+        # the same work, one sample per process on every host core (the reference is single-threaded: reported for
+        # completeness)
+        from oracle import cpu_bench
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        v, wall, nproc = cpu_bench.all_cores(test_all[0], test_all[1], p_all, phi_all, chrom_off, start, end, fit, ncores)
+        extra = {"all_cores": {"value": v, "unit": "exons*samples/s", "cores": nproc, "wall_s": wall,
+                               "sample": "%d samples x %d exons, one process per core, same work per sample" % (nproc, test_h.shape[0])}}
+    return {**extra, "value": cells / (t_emit + t_vit + t_fit), "unit": "exons*samples/s", "cores": 1, "kind": "port",
             "sample": "%d samples x %d exons of the same synthetic batch: emissions + Viterbi + call table with the "
                       "oracle's libm flavour (bit-identical to the reference's compiled lnbeta), single thread%s"
                       % (n_s, test_h.shape[0],
@@ -91,6 +100,8 @@ def main():
     ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
     ap.add_argument("--phi-bins", type=int, default=1, help="> 1: the depth-binned dispersion model (phi.bins, csrc/edbins.inc); "
                     "an optional mode, not the headline configuration")
+    ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
+                    "(process-level parallelism; reported inside cpu_baseline.all_cores)")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -222,8 +233,13 @@ def main():
         }
         if world == 1 and args.cpu_samples > 0:
             k = min(args.cpu_samples, S)
+            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            ka = min(ncores, S) if args.cpu_all_cores else 0
             out["cpu_baseline"] = cpu_baseline(test[:, :k].cpu().numpy(), ref[:, :k].cpu().numpy(),
-                                               p[:k].cpu().numpy(), phi[:k].cpu().numpy(), chrom_off, start, end, bool(args.fit))
+                                               p[:k].cpu().numpy(), phi[:k].cpu().numpy(), chrom_off, start, end, bool(args.fit),
+                                               allcores=ka > 0,
+                                               test_all=(test[:, :ka].cpu().numpy(), ref[:, :ka].cpu().numpy()) if ka else None,
+                                               p_all=p[:ka].cpu().numpy() if ka else None, phi_all=phi[:ka].cpu().numpy() if ka else None)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     batch.close()
