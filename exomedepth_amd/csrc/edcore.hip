@@ -162,6 +162,10 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       obs = test[cell];
       tot = obs + ref[cell];   // as.integer(reference + test), R/class_definition.R:187
     }
+    // A cell without reads: a1 + 0 and (a2 + 0) - 0 are a1 and a2 themselves, so the reference's second log-Beta
+    // call repeats the per-sample one bit for bit (same value, same GSL error) -- no task, the result is c - c
+    // (exactly +0; NaN if c is not finite).  ~14 % of the exons of the bundled exome data have no reads.
+    const bool empty = live && obs == 0 && tot == 0;
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
       double x = 1.0, y = 1.0;
@@ -170,14 +174,14 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
         const double a2 = consts[(st * 3 + 1) * S + s];
         x = a1 + (double)obs;                       // src/CNV_estimate.cpp:49
         y = (a2 + (double)tot) - (double)obs;
-        nflag += cflags[st * S + s];
+        nflag += cflags[st * S + s] * (empty ? 2 : 1);
       }
       const bool pos = (x > 0.0 && y > 0.0);
       const double mx = (x > y ? x : y);
       const double mn = (x < y ? x : y);
       const double rat = mn / mx;
-      const bool front = live && pos && (rat < 0.2);
-      const bool back = live && !front;
+      const bool front = live && !empty && pos && (rat < 0.2);
+      const bool back = live && !empty && !front;
       // wave-aggregated slot allocation
       const unsigned long long mf = __ballot(front), mb = __ballot(back);
       const unsigned long long below = (1ull << lane) - 1ull;
@@ -188,7 +192,7 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       }
       basef = __shfl(basef, 0, 64);
       baseb = __shfl(baseb, 0, 64);
-      int sl = -1;
+      int sl = empty ? -2 : -1;
       if (front) {
         sl = basef + __popcll(mf & below);
         t_a[sl] = mn; t_b[sl] = mx; t_r[sl] = rat;
@@ -223,7 +227,9 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
 #pragma unroll
       for (int st = 0; st < 3; ++st) {
         const double c = consts[(st * 3 + 2) * S + s];
-        loglik[(e * 3 + st) * S + s] = t_a[slot[k * 3 + st]] - c;
+        const int sl = slot[k * 3 + st];
+        const double v = t_a[sl < 0 ? 0 : sl];
+        loglik[(e * 3 + st) * S + s] = (sl == -2 ? c : v) - c;
       }
     }
   }

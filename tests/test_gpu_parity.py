@@ -274,3 +274,33 @@ def test_batch_empty_chromosomes(edlib, oracle):
         ep, ec = oracle.callcnvs(ll, chrom_off, start, end)
         assert np.array_equal(path[:, s].astype(np.int8), ep)
     batch.close(); plan.close()
+
+
+def test_batch_cells_without_reads_and_error_count(edlib, oracle):
+    """Cells with test = reference = 0 take a shortcut on the device (the second log-Beta call of the reference
+    repeats the per-sample one): the likelihood must still be the checker's bit for bit -- +0 exactly, NaN for a
+    sample whose constants are not finite -- and the count of GSL error events must match the checker's."""
+    from exomedepth_amd import synth
+    E, S, C = 1500, 6, 3
+    chrom_off, start, end = synth.exon_design(E, C, 33)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 33, n_segments=2, mean_depth=50.0)
+    rng = np.random.default_rng(4)
+    dead = rng.random((E, S)) < 0.15
+    test[dead] = 0; ref[dead] = 0
+    test[:, 2] = 0; ref[:, 2] = 0          # a sample without any read
+    p = p.copy(); phi = phi.copy()
+    p[4] = 0.0                              # expected = 0: shape parameters 0/0 -> GSL domain errors, rows of NaN/0
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    batch.run(test, ref, phi, p)
+    ll = batch.loglik()
+    nerr = batch.n_gsl_errors()
+    batch.close(); plan.close()
+    exp_err = 0
+    for s in range(S):
+        exp_ll, e = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.PORTABLE)
+        assert np.array_equal(bits(ll[:, :, s]), bits(exp_ll)), "sample %d" % s
+        exp_err += e
+        if s not in (4,):
+            assert np.all(ll[dead[:, s], :, s] == 0.0) and not np.any(np.signbit(ll[dead[:, s], :, s]))
+    assert nerr == exp_err and exp_err > 0
