@@ -709,7 +709,7 @@ k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chr
   const int64_t off = offsets[s * C + c];
   const uint32_t* __restrict__ pp = ppath + word_off[c] * S + s;
   const int64_t nw = (m + kVitTile - 1) / kVitTile;   // unused high bits of the last word are zero
-  constexpr int kW = 8;
+  constexpr int kW = 16;
   int64_t start = -1;
   int nexons = 0, prev = 0, k = 0;
   auto step = [&](int cur, int64_t x) {
@@ -735,10 +735,16 @@ k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chr
     if (cur != 0) ++nexons;
     prev = cur;
   };
+  uint32_t nxt[kW];   // the next kW words are requested before the current ones are walked (the loop is latency-bound:
+                      // nearly every word is all-normal and skipped)
+#pragma unroll
+  for (int t = 0; t < kW; ++t) nxt[t] = (t < nw) ? pp[(int64_t)t * S] : 0u;
   for (int64_t wb = 0; wb < nw && __any(k < todo); wb += kW) {
     uint32_t w[kW];
 #pragma unroll
-    for (int t = 0; t < kW; ++t) w[t] = (wb + t < nw) ? pp[(wb + t) * S] : 0u;
+    for (int t = 0; t < kW; ++t) w[t] = nxt[t];
+#pragma unroll
+    for (int t = 0; t < kW; ++t) nxt[t] = (wb + kW + t < nw) ? pp[(wb + kW + t) * S] : 0u;
 #pragma unroll
     for (int t = 0; t < kW; ++t) {
       if ((w[t] | (uint32_t)prev) == 0) continue;
