@@ -122,6 +122,7 @@ constexpr int kEmitCells = 2;                                // cells per thread
 constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per workgroup
 constexpr int kEmitRows = kEmitCells * kEmitBlock / 64;      // exons per workgroup tile (x 64 samples)
 constexpr int64_t kEmitHeadBlocks = 2048;                    // workgroups of a group's short leading launch (ed_batch_run)
+constexpr int kSideStreams = 3;                              // HIP maps streams onto 4 hardware queues: main + 3
 
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
@@ -1359,9 +1360,9 @@ struct ed_batch {
   int32_t n_jobs = 0;
   std::vector<std::vector<int>> jobs;   // host copy: chromosomes of each Viterbi job
   std::vector<int32_t> group_off;       // job ranges of the overlap groups
-  hipStream_t side = nullptr;           // second stream: Viterbi jobs overlap the emissions of later jobs
+  std::vector<hipStream_t> sides;       // side streams (groups round-robin): Viterbi overlaps the emissions of later groups
   std::vector<hipEvent_t> job_ev;       // emissions of group g are complete
-  hipEvent_t join_ev = nullptr;
+  std::vector<hipEvent_t> join_ev;      // Viterbi (+ trace-back) of group g is complete
   double* d_consts = nullptr;
   int* d_cflags = nullptr;
   int32_t* d_counts = nullptr;
@@ -1686,62 +1687,80 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
       return la != lb ? la > lb : a < bb; });
     std::vector<std::vector<int>> jobs;
     for (int c : order) jobs.push_back(std::vector<int>(1, c));
-    // How many groups?  Overlap only pays when the emissions of the later groups are long enough to cover
-    // the Viterbi of the earlier ones; for a small batch the groups' critical paths would simply add up on
-    // the side stream.  A two-constant cost model picks the cut set with the smallest estimated makespan
-    // (measured on MI355X: emissions ~5.5e-11 s per cell; a chain step ~1.9e-7 s, forward + trace-back,
-    // until the waves outnumber the SIMDs ~2:1).
-    const std::vector<std::vector<double>> candidates = {{1.0}, {0.55, 1.0}, {0.40, 0.72, 0.90, 1.0}};
+    // How to cut the jobs (longest chromosome first) into groups?  A group's Viterbi runs on a side stream as soon
+    // as the group's emissions are done.  HIP multiplexes streams onto 4 hardware queues, and streams that share
+    // a queue serialise (seen in the kernel trace: with 7 side streams the emissions themselves waited behind
+    // Viterbi kernels), so there are kSideStreams = 3 side streams, used round-robin; a group's chains finish at
+    // max(its emissions done, its stream free) + (its longest chain) -- slower when the resident Viterbi waves
+    // outnumber the SIMDs.
+    // Small batches want the long chromosomes in groups of their own, issued first, so that their chains start
+    // early; large batches want few groups (every group boundary costs a short extra launch and the tail of
+    // an emission launch).  A two-constant cost model picks among a handful of cut sets (measured on MI355X:
+    // emissions 5.4e-11 s per cell; 6.5e-8 s per chain step, forward + trace-back).
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, plan->device));
     const double simds = 4.0 * prop.multiProcessorCount;
-    const double c_emit = 5.5e-11, c_step = 1.9e-7;
-    auto build_groups = [&](const std::vector<double>& cuts, std::vector<int32_t>& goff) {
-      goff.assign(1, 0);
+    const double c_emit = 5.4e-11, c_step = 6.5e-8, c_launch = 1.5e-5;
+    const int32_t J = (int32_t)jobs.size();
+    std::vector<std::vector<int32_t>> candidates;
+    auto by_fraction = [&](const std::vector<double>& cuts) {
+      std::vector<int32_t> goff(1, 0);
       int64_t run = 0;
       size_t gi = 0;
-      for (size_t k = 0; k < jobs.size(); ++k) {
+      for (int32_t k = 0; k < J; ++k) {
         run += plan->chrom_off[jobs[k][0] + 1] - plan->chrom_off[jobs[k][0]];
-        while (gi + 1 < cuts.size() && (double)run >= cuts[gi] * (double)total && k + 1 < jobs.size()) {
-          if ((int32_t)(k + 1) > goff.back()) goff.push_back((int32_t)(k + 1));
+        while (gi + 1 < cuts.size() && (double)run >= cuts[gi] * (double)total && k + 1 < J) {
+          if (k + 1 > goff.back()) goff.push_back(k + 1);
           ++gi;
         }
       }
-      if (goff.back() != (int32_t)jobs.size()) goff.push_back((int32_t)jobs.size());
+      if (goff.back() != J) goff.push_back(J);
+      return goff;
     };
+    auto by_index = [&](std::vector<int32_t> idx) {
+      std::vector<int32_t> goff(1, 0);
+      for (int32_t v : idx) if (v > goff.back() && v < J) goff.push_back(v);
+      if (goff.back() != J) goff.push_back(J);
+      return goff;
+    };
+    candidates.push_back(by_fraction({1.0}));
+    candidates.push_back(by_fraction({0.55, 1.0}));
+    candidates.push_back(by_fraction({0.40, 0.72, 0.90, 1.0}));
+    candidates.push_back(by_index({1}));
+    candidates.push_back(by_index({1, 3}));
+    candidates.push_back(by_index({1, 3, 8}));
+    candidates.push_back(by_index({1, 2, 4, 10}));
     double best_cost = 1e300;
-    for (const auto& cuts : candidates) {
-      std::vector<int32_t> goff;
-      build_groups(cuts, goff);
-      double t_main = 0.0, t_side = 0.0;
+    for (const auto& goff : candidates) {
+      double t_main = 0.0, finish = 0.0, waves = 0.0;
+      double busy[kSideStreams] = {0.0, 0.0, 0.0};   // when each side stream becomes free
       for (size_t g = 0; g + 1 < goff.size(); ++g) {
         int64_t exons = 0, longest = 0;
         for (int k = goff[g]; k < goff[g + 1]; ++k) {
           const int64_t mc = plan->chrom_off[jobs[k][0] + 1] - plan->chrom_off[jobs[k][0]];
           exons += mc; longest = std::max(longest, mc);
         }
-        t_main += c_emit * (double)exons * (double)S;
-        const double waves = (double)(goff[g + 1] - goff[g]) * std::ceil((double)S / kVitChains);
+        t_main += c_emit * (double)exons * (double)S + (g > 0 ? c_launch : 0.0);
+        waves += (double)(goff[g + 1] - goff[g]) * std::ceil((double)S / kVitChains);   // (earlier groups still running)
         const double vit = c_step * (double)longest * std::max(1.0, waves / (2.0 * simds));
-        t_side = std::max(t_side, t_main) + vit;
+        double& q = busy[g % kSideStreams];
+        q = std::max(q, t_main) + vit;
+        finish = std::max(finish, q);
       }
-      const double cost = std::max(t_main, t_side);
+      const double cost = std::max(t_main, finish);
       if (cost < best_cost) { best_cost = cost; b->group_off = goff; }
     }
     std::vector<int32_t> joff(1, 0), jchr;
     for (auto& jb : jobs) { for (int c : jb) jchr.push_back(c); joff.push_back((int32_t)jchr.size()); }
     b->n_jobs = (int32_t)jobs.size();
     b->jobs = jobs;
-    {
-      // the latency-bound Viterbi workgroups must not queue behind the thousands of pending emission
-      // workgroups of the next group: the side stream gets the highest dispatch priority
-      int least = 0, greatest = 0;
-      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIP_TRY(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, greatest));
-    }
-    b->job_ev.resize(b->group_off.size());
+    const size_t n_groups = b->group_off.size() - 1;
+    b->sides.resize(std::min<size_t>(n_groups, kSideStreams));
+    for (auto& sd : b->sides) HIP_TRY(hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
+    b->job_ev.resize(n_groups);
     for (auto& e : b->job_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
+    b->join_ev.resize(n_groups);
+    for (auto& e : b->join_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void**)&b->d_job_off, joff.size() * 4));
     HIP_TRY(hipMalloc((void**)&b->d_job_chrom, std::max<size_t>(jchr.size(), 1) * 4));
     HIP_TRY(hipMemcpy(b->d_job_off, joff.data(), joff.size() * 4, hipMemcpyHostToDevice));
@@ -1773,8 +1792,8 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
-  if (b->join_ev) (void)hipEventDestroy(b->join_ev);
-  if (b->side) (void)hipStreamDestroy(b->side);
+  for (auto& e : b->join_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& sd : b->sides) if (sd) (void)hipStreamDestroy(sd);
   delete b;
 }
 
@@ -1840,7 +1859,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       // previous group's Viterbi workgroups (side stream) are dispatched into the slots freed at that launch
       // boundary instead of queueing behind this group's thousands of pending workgroups.
       const int64_t blk0 = b->seg[3 * j0], nblk = (bins > 0) ? 0 : b->seg[3 * j1] - blk0;
-      const int64_t head = (g > 0) ? std::min<int64_t>(nblk, kEmitHeadBlocks) : 0;
+      const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
       if (bins > 0 && g == 0)   // one launch over every cell; the Viterbi groups follow it
         hipLaunchKernelGGL(k_emit_bins, dim3((unsigned)((cells + kEmitBlock - 1) / kEmitBlock)), dim3(kEmitBlock), 0, st, d_test,
                            d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S, b->d_loglik, b->d_nerr);
@@ -1851,21 +1870,22 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
                            b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, (uint32_t)((S + 63) / 64), b->d_loglik, b->d_nerr);
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
-      HIP_TRY(hipStreamWaitEvent(b->side, b->job_ev[g], 0));
+      hipStream_t side = b->sides[g % b->sides.size()];
+      HIP_TRY(hipStreamWaitEvent(side, b->job_ev[g], 0));
       const dim3 gw((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)(j1 - j0));
       hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
-                         b->side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
+                         side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
                          b->d_last, b->d_job_off, b->d_job_chrom, j0);
-      hipLaunchKernelGGL(k_tb_maps, gw, dim3(256), 0, b->side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, b->d_job_off,
+      hipLaunchKernelGGL(k_tb_maps, gw, dim3(256), 0, side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, b->d_job_off,
                          b->d_job_chrom, j0, b->d_maps);
-      hipLaunchKernelGGL(k_tb_chain, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)(j1 - j0)), dim3(kWave), 0, b->side,
+      hipLaunchKernelGGL(k_tb_chain, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)(j1 - j0)), dim3(kWave), 0, side,
                          p->d_chrom_off, p->d_tile_off, S, b->d_job_off, b->d_job_chrom, j0, b->d_last, b->d_maps, b->d_ent);
-      hipLaunchKernelGGL(k_tb_paths, gw, dim3(256), 0, b->side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, C, b->d_job_off,
+      hipLaunchKernelGGL(k_tb_paths, gw, dim3(256), 0, side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, C, b->d_job_off,
                          b->d_job_chrom, j0, b->d_ent, b->d_ppath, b->d_path, b->d_counts);
+      HIP_TRY(hipEventRecord(b->join_ev[g], side));
     }
     if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));   // all emissions issued and done on the main stream
-    HIP_TRY(hipEventRecord(b->join_ev, b->side));
-    HIP_TRY(hipStreamWaitEvent(st, b->join_ev, 0));
+    for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) HIP_TRY(hipStreamWaitEvent(st, b->join_ev[g], 0));
   }
   if (b->fused && C > 0 && cells > 0 && p->max_words > 0)   // (the two-kernel path writes the byte path in k_tb_paths)
     hipLaunchKernelGGL(k_path_expand, dim3((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)C), dim3(256),
@@ -2029,7 +2049,7 @@ ED_EXPORT int ed_batch_n_emit_launches(const ed_batch* b)
   int n = 0;
   for (size_t g = 0; g + 1 < b->group_off.size(); ++g) {
     const int64_t nblk = b->seg[3 * b->group_off[g + 1]] - b->seg[3 * b->group_off[g]];
-    const int64_t head = (g > 0) ? std::min<int64_t>(nblk, kEmitHeadBlocks) : 0;
+    const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
     n += (head > 0) + (nblk - head > 0);
   }
   return n;
