@@ -1105,74 +1105,100 @@ constexpr int kHistKy = 1024;                            // bins of the test cou
 constexpr int kHistKr = 4096;                            // bins of the reference count
 constexpr int kHistKn = 4096;                            // bins of the total
 constexpr int kHistK = kHistKy + kHistKr + kHistKn;
-constexpr int kHistSamples = 4;                          // samples per workgroup: 4 x 9216 x 4 B = 147 456 B of LDS
+constexpr int kHistSamples = 8;                          // samples per workgroup: 8 x 9216 x 2 B = 147 456 B of LDS
 constexpr int kHistBlock = 1024;
+constexpr int kHistHalves = 2;                           // workgroups per sample group: each takes half of the rows
+constexpr int kHistRows = kHistBlock / kHistSamples;     // rows per sweep of a workgroup
+constexpr int kHistGroups = kHistHalves * kHistRows;     // (half, thread row) pairs = overflow regions per sample
+constexpr int kHistChunk = 65535;                        // rows between flushes: a 16-bit bin cannot wrap
+static_assert((kHistKy % 2) == 0 && (kHistKr % 2) == 0, "two 16-bit bins per LDS word");
 
+// LDS bins are 16 bits wide, two per 32-bit word (the LDS atomic adds 1 or 1 << 16): 8 samples fit where 4 did,
+// which halves the L2 -> L1 line traffic the kernel is bound by (a workgroup uses 32 B of every 128-B line of a
+// count row instead of 16).  A bin cannot wrap because the bins are flushed to the 32-bit global histogram of
+// this half every kHistChunk rows.  hist: [kHistHalves][kHistK][S].
 __global__ void __launch_bounds__(kHistBlock)
 k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t rs, int64_t E, int64_t S,
            uint32_t* __restrict__ hist, int32_t* __restrict__ ov_y, int32_t* __restrict__ ov_r, int32_t* __restrict__ ovn,
-           int64_t cap)   // cap: overflow cells per (row group, sample); row group t = tid / 4 owns rows t, t + 256, ...
+           int64_t cap)   // cap: overflow cells per (overflow region, sample)
 {
-  __shared__ uint32_t hsm[kHistSamples * kHistK];
+  __shared__ uint32_t hsm[kHistSamples * (kHistK / 2)];
   const int tid = threadIdx.x;
-  for (int i = tid; i < kHistSamples * kHistK; i += kHistBlock) hsm[i] = 0;
-  __syncthreads();
-  // Workgroups are dealt to the 8 XCDs round-robin, and 8 neighbouring sample quads share every 128-byte line of
-  // a count row: neighbours must sit on the SAME XCD (one L2) or each line is fetched up to 8 times.  So XCD x
-  // (= blockIdx % 8) owns the contiguous quads [x * per, (x + 1) * per).
-  const int64_t nq = (S + kHistSamples - 1) / kHistSamples, per = (nq + 7) / 8;
-  const int64_t quad = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  // Workgroups are dealt to the 8 XCDs round-robin, and neighbouring sample groups share every 128-byte line of a
+  // count row: neighbours must sit on the SAME XCD (one L2) or each line is fetched several times.  So XCD x
+  // (= blockIdx % 8) owns a contiguous range of the (half, sample group) pairs, half-major.
+  const int64_t ng = (S + kHistSamples - 1) / kHistSamples, nwg = ng * kHistHalves, per = (nwg + 7) / 8;
+  const int64_t lin = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const bool active = (int64_t)(blockIdx.x >> 3) < per && lin < nwg;
+  const int half = active ? (int)(lin / ng) : 0;
+  const int64_t grp = active ? lin % ng : 0;
   const int j = tid & (kHistSamples - 1);
-  const int64_t s = (quad < nq && (int64_t)(blockIdx.x >> 3) < per) ? quad * kHistSamples + j : S;
-  uint32_t* __restrict__ h = hsm + j * kHistK;
+  const int64_t s = active ? grp * kHistSamples + j : S;
+  uint32_t* __restrict__ h = hsm + j * (kHistK / 2);
+  uint32_t* __restrict__ hg = hist + (int64_t)half * kHistK * S;
+  // this half's rows
+  const int64_t r0 = (E * half) / kHistHalves, r1 = (E * (half + 1)) / kHistHalves;
   int nov = 0;   // this thread's overflow cells: stored in row order in its own region -- no atomics, and the
                  // order in which k_fit_hnewton adds them up is the same on every run
-  constexpr int kRows = kHistBlock / kHistSamples;   // rows per sweep of the workgroup = row groups
-  const int64_t ovbase = (int64_t)(tid / kHistSamples) * cap;
-  if (s < S) {
-    constexpr int kPre = 4;                              // rows in flight per thread
-    int yb[kPre], rb[kPre];
-    const int64_t e0 = tid / kHistSamples;
-#pragma unroll
-    for (int k = 0; k < kPre; ++k) {
-      const int64_t e = e0 + (int64_t)k * kRows;
-      yb[k] = (e < E) ? test[e * rs + s] : 0;
-      rb[k] = (e < E) ? ref[e * rs + s] : 0;
-    }
-    for (int64_t e = e0; e < E; e += (int64_t)kPre * kRows) {
-      int yc[kPre], rc[kPre];
-#pragma unroll
-      for (int k = 0; k < kPre; ++k) { yc[k] = yb[k]; rc[k] = rb[k]; }
+  const int region = half * kHistRows + tid / kHistSamples;
+  const int64_t ovbase = (int64_t)region * cap;
+  auto bump = [&](int v) { atomicAdd(&h[v >> 1], 1u << ((v & 1) * 16)); };
+  int chunk_no = 0;
+  for (int64_t c0 = r0; c0 < r1 || chunk_no == 0; c0 += kHistChunk, ++chunk_no) {
+    const int64_t c1 = (c0 + kHistChunk < r1) ? c0 + kHistChunk : r1;
+    for (int i = tid; i < kHistSamples * (kHistK / 2); i += kHistBlock) hsm[i] = 0;
+    __syncthreads();
+    if (s < S) {
+      constexpr int kPre = 4;                              // rows in flight per thread
+      int yb[kPre], rb[kPre];
+      const int64_t e0 = c0 + tid / kHistSamples;
 #pragma unroll
       for (int k = 0; k < kPre; ++k) {
-        const int64_t en = e + (int64_t)(kPre + k) * kRows;
-        yb[k] = (en < E) ? test[en * rs + s] : 0;
-        rb[k] = (en < E) ? ref[en * rs + s] : 0;
+        const int64_t e = e0 + (int64_t)k * kHistRows;
+        yb[k] = (e < c1) ? test[e * rs + s] : 0;
+        rb[k] = (e < c1) ? ref[e * rs + s] : 0;
       }
+      for (int64_t e = e0; e < c1; e += (int64_t)kPre * kHistRows) {
+        int yc[kPre], rc[kPre];
 #pragma unroll
-      for (int k = 0; k < kPre; ++k) {
-        if (e + (int64_t)k * kRows >= E) break;
-        const int y = yc[k], r = rc[k];
-        const int n = y + r;
-        if (n <= 0) continue;   // carries no information (and is not counted), as in accumulate_cell
-        if ((unsigned)y < (unsigned)kHistKy && (unsigned)r < (unsigned)kHistKr && (unsigned)n < (unsigned)kHistKn) {
-          atomicAdd(&h[y], 1u);
-          atomicAdd(&h[kHistKy + r], 1u);
-          atomicAdd(&h[kHistKy + kHistKr + n], 1u);
-        } else {
-          if (nov < cap) { ov_y[(ovbase + nov) * S + s] = y; ov_r[(ovbase + nov) * S + s] = r; }
-          ++nov;
+        for (int k = 0; k < kPre; ++k) { yc[k] = yb[k]; rc[k] = rb[k]; }
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+          const int64_t en = e + (int64_t)(kPre + k) * kHistRows;
+          yb[k] = (en < c1) ? test[en * rs + s] : 0;
+          rb[k] = (en < c1) ? ref[en * rs + s] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+          if (e + (int64_t)k * kHistRows >= c1) break;
+          const int y = yc[k], r = rc[k];
+          const int n = y + r;
+          if (n <= 0) continue;   // carries no information (and is not counted), as in accumulate_cell
+          if ((unsigned)y < (unsigned)kHistKy && (unsigned)r < (unsigned)kHistKr && (unsigned)n < (unsigned)kHistKn) {
+            bump(y);
+            bump(kHistKy + r);
+            bump(kHistKy + kHistKr + n);
+          } else {
+            if (nov < cap) { ov_y[(ovbase + nov) * S + s] = y; ov_r[(ovbase + nov) * S + s] = r; }
+            ++nov;
+          }
         }
       }
     }
+    __syncthreads();
+    // flush: this workgroup owns its (half, samples) slice of the global histogram
+    for (int i = tid; i < kHistSamples * kHistK; i += kHistBlock) {
+      const int v = i / kHistSamples, jj = i % kHistSamples;
+      const int64_t ss = grp * kHistSamples + jj;
+      if (active && ss < S) {
+        const uint32_t cnt = (hsm[jj * (kHistK / 2) + (v >> 1)] >> ((v & 1) * 16)) & 0xffffu;
+        uint32_t* __restrict__ o = hg + (int64_t)v * S + ss;
+        *o = (chunk_no == 0 ? 0u : *o) + cnt;
+      }
+    }
+    __syncthreads();
   }
-  if (s < S) ovn[(int64_t)(tid / kHistSamples) * S + s] = nov;
-  __syncthreads();
-  for (int i = tid; i < kHistSamples * kHistK; i += kHistBlock) {
-    const int v = i / kHistSamples, jj = i % kHistSamples;
-    const int64_t ss = quad * kHistSamples + jj;
-    if (quad < nq && ss < S) hist[(int64_t)v * S + ss] = hsm[jj * kHistK + v];
-  }
+  if (s < S) ovn[(int64_t)region * S + s] = nov;
 }
 
 // All Newton iterations of 4 samples in one launch: 256 strands per sample share the bins and the overflow
@@ -1180,7 +1206,6 @@ k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, in
 // strand 0 takes the step.
 constexpr int kHnS = 4;    // samples per workgroup
 constexpr int kHnY = 256;  // strands per sample
-constexpr int kHistGroups = kHistBlock / kHistSamples;   // overflow regions per sample (row groups of k_fit_hist)
 static_assert(kHistGroups % kHnY == 0, "every strand owns whole overflow regions");
 
 __global__ void __launch_bounds__(kHnS * kHnY)
@@ -1224,7 +1249,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
       const double p = 1.0 / (1.0 + ed_pexp(-sh_eta[lane]));
       const double a = th * p, b = th * (1.0 - p);
       for (int v = y; v < kHistKy; v += kHnY) {
-        const uint32_t c = hist[(int64_t)v * S + sc];
+        const uint32_t c = hist[(int64_t)v * S + sc] + hist[((int64_t)kHistK + v) * S + sc];
         if (c) {
           double ps, p1;
           edfit::digamma_trigamma(a + (double)v, ps, p1);
@@ -1232,7 +1257,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
         }
       }
       for (int v = y; v < kHistKr; v += kHnY) {
-        const uint32_t c = hist[(int64_t)(kHistKy + v) * S + sc];
+        const uint32_t c = hist[(int64_t)(kHistKy + v) * S + sc] + hist[((int64_t)kHistK + kHistKy + v) * S + sc];
         if (c) {
           double ps, p1;
           edfit::digamma_trigamma(b + (double)v, ps, p1);
@@ -1240,7 +1265,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
         }
       }
       for (int v = y; v < kHistKn; v += kHnY) {
-        const uint32_t c = hist[(int64_t)(kHistKy + kHistKr + v) * S + sc];
+        const uint32_t c = hist[(int64_t)(kHistKy + kHistKr + v) * S + sc] + hist[((int64_t)kHistK + kHistKy + kHistKr + v) * S + sc];
         if (c) {
           double ps, p1;
           edfit::digamma_trigamma(th + (double)v, ps, p1);
@@ -1915,7 +1940,7 @@ struct FitWork {
   double* eta = nullptr;
   double* lam = nullptr;
   int* done = nullptr;
-  uint32_t* hist = nullptr;    // [kHistK][S] count histograms (k_fit_hist)
+  uint32_t* hist = nullptr;    // [kHistHalves][kHistK][S] count histograms (k_fit_hist)
   int32_t* ov_y = nullptr;     // [kHistGroups][ov_cap][S] cells beyond the histogram range, per row group of k_fit_hist
   int32_t* ov_r = nullptr;
   int32_t* ovn = nullptr;      // [kHistGroups][S] overflow cells of each (row group, sample)
@@ -1926,7 +1951,7 @@ struct FitWork {
     if (hist) return ED_OK;
     const int64_t E = E_max;   // sized for the largest fit this workspace serves
     ov_cap = std::max<int64_t>(8, (E / kHistGroups) / 8 + 1);   // per (row group, sample): ~1/8 of the group's rows
-    HIP_TRY(hipMalloc((void**)&hist, (size_t)kHistK * S * 4));
+    HIP_TRY(hipMalloc((void**)&hist, (size_t)kHistHalves * kHistK * S * 4));
     HIP_TRY(hipMalloc((void**)&ov_y, (size_t)ov_cap * kHistGroups * S * 4));
     HIP_TRY(hipMalloc((void**)&ov_r, (size_t)ov_cap * kHistGroups * S * 4));
     HIP_TRY(hipMalloc((void**)&ovn, (size_t)kHistGroups * S * 4));
@@ -1976,7 +2001,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   if (use_hist) {
     if (tcs != 1 || trs != rrs) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
     if (int rc = w.alloc_hist()) return rc;
-    hipLaunchKernelGGL(k_fit_hist, dim3((unsigned)(((((S + kHistSamples - 1) / kHistSamples) + 7) / 8) * 8)), dim3(kHistBlock), 0, st, d_test, d_ref,
+    hipLaunchKernelGGL(k_fit_hist, dim3((unsigned)((((S + kHistSamples - 1) / kHistSamples * kHistHalves + 7) / 8) * 8)), dim3(kHistBlock), 0, st, d_test, d_ref,
                        rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap);
     hipLaunchKernelGGL(k_fit_hnewton, dim3((unsigned)((S + kHnS - 1) / kHnS)), dim3(kHnS, kHnY), 0, st, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap, S,
                        w.eta, w.lam, w.done, 40, 1e-6);
