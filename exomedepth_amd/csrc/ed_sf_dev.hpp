@@ -314,6 +314,33 @@ __device__ __forceinline__ double lnbeta_ratio(double mn, double mx, double rat)
   return lnpre + ((t1 - t2) - t3);
 }
 
+// The same with Gamma*(mn) and log(mn) handed in (g > 0: g = Gamma*(mn), l = log(mn)), or with Gamma*(mx) handed in
+// (g < 0: -g = Gamma*(mx)), or with nothing known (g NaN).  Gamma* of a positive argument is positive, so the sign
+// is free to carry that bit.  The values must come from gammastar_pos / plog_fast themselves: same bits.
+__device__ __forceinline__ double lnbeta_ratio_pre(double mn, double mx, double rat, double g, double l)
+{
+  const bool have_mn = g > 0.0;
+  const double gsa = have_mn ? g : gammastar_pos(mn);
+  const double gsb = (g < 0.0) ? -g : gammastar_pos(mx);
+  const double gsxy = gammastar_pos(mn + mx);
+  const double lnopr = log1plusx_ratio(rat);
+  const double lnpre = plog_fast((fdiv(gsa * gsb, gsxy) * EDSF_M_SQRT2) * EDSF_M_SQRTPI);
+  const double t1 = mn * plog_fast(rat);
+  const double t2 = 0.5 * (have_mn ? l : plog_fast(mn));
+  const double t3 = ((mn + mx) - 0.5) * lnopr;
+  return lnpre + ((t1 - t2) - t3);
+}
+
+// +inf arguments reach this route with rat = NaN; the arithmetic then yields NaN as the reference's does.
+// (lgx handed in, from lngamma_pos(x, false) itself; NaN = not known)
+__device__ __forceinline__ double lnbeta_general_pre(double x, double y, double lgx_in)
+{
+  const double lgx = (lgx_in == lgx_in) ? lgx_in : lngamma_pos(x, false);
+  const double lgy = lngamma_pos(y, false);
+  const double lgxy = lngamma_pos(x + y, false);
+  return (lgx + lgy) - lgxy;
+}
+
 // +inf arguments reach this route with rat = NaN; the arithmetic then yields NaN as the reference's does.
 __device__ __forceinline__ double lnbeta_general(double x, double y)
 {

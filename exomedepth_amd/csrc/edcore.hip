@@ -68,6 +68,7 @@ static int require_device()
 namespace {
 
 constexpr int kEmitBlock = 256;
+constexpr int kEmitTab = 1024;   // test counts covered by the per-sample tables (k_emit_tables)
 constexpr int kWave = 64;
 
 // myprob's shape parameters for one state (src/CNV_estimate.cpp:45-46)
@@ -110,6 +111,35 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
   }
 }
 
+// x = a1 + observed is the only argument of three of the terms of log B(x, y): Gamma*(x) and log(x) on the ratio
+// route (when x is the smaller argument -- the usual case, the test sample being one of ~10), log Gamma(x) on the
+// general route.  For a sample and a state a1 is a constant and `observed` a small integer, so these terms are
+// tabulated per (sample, state, observed < kEmitTab) before the emission kernel runs -- by the very functions the
+// routes call, hence the same bits -- and the emission kernel gathers them instead of evaluating them: about a
+// quarter of its arithmetic.  The gathers stay in L2: XCD x only ever works on sample blocks x, x + 8, ...
+//   tab_gl [3][kEmitTab][S] double2 (Gamma*(x), log x)      tab_lg [3][kEmitTab][S] double  log Gamma(x)
+__global__ void __launch_bounds__(256)
+k_emit_tables(const double* __restrict__ consts, int64_t S, double2* __restrict__ tab_gl, double* __restrict__ tab_lg)
+{
+  const int64_t s = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int obs = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int st = blockIdx.z;
+  if (s >= S || obs >= kEmitTab) return;
+  const double x = consts[(st * 3 + 0) * S + s] + (double)obs;   // src/CNV_estimate.cpp:49
+  double2 gl;
+  double lg;
+  if (x > 0.0 && x < HUGE_VAL) {
+    gl.x = edsf::gammastar_pos(x);
+    gl.y = edsf::plog_fast(x);
+    lg = edsf::lngamma_pos(x, false);
+  } else {
+    gl.x = gl.y = lg = ed_pm_nan();   // not tabulated: the task evaluates (or takes the cold path) itself
+  }
+  const int64_t i = ((int64_t)st * kEmitTab + obs) * S + s;
+  tab_gl[i] = gl;
+  tab_lg[i] = lg;
+}
+
 // Emissions for the batch.  Each (cell, state) pair is one log-Beta *task*; a task takes one of two
 // value-exact routes (ratio / general, see ed_sf_dev.hpp) that differ ~1.5x in cost and that adjacent
 // cells pick differently (the selector is min/max < 0.2 of the shape parameters, src/beta.c:64-69).
@@ -118,7 +148,7 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
 // array, all others from the back, so every wave of the evaluation phase but at most one runs a
 // single route.  Cells are numbered exon-major / sample-minor: a wave reads 64 consecutive samples of
 // one exon (coalesced) and writes three coalesced rows of the [E][3][S] likelihood matrix.
-constexpr int kEmitCells = 2;                                // cells per thread
+constexpr int kEmitCells = 1;                                // cells per thread
 constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per workgroup
 constexpr int kEmitRows = kEmitCells * kEmitBlock / 64;      // exons per workgroup tile (x 64 samples)
 constexpr int64_t kEmitHeadBlocks = 2048;                    // workgroups of a group's short leading launch (ed_batch_run)
@@ -127,11 +157,14 @@ constexpr int kSideStreams = 3;                              // HIP maps streams
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
              const int* __restrict__ cflags, const int64_t* __restrict__ seg, int nseg, int64_t blk_base, int64_t S,
-             uint32_t nsb, double* __restrict__ loglik, unsigned long long* __restrict__ nerr)
+             uint32_t nsb, const double2* __restrict__ tab_gl, const double* __restrict__ tab_lg,
+             double* __restrict__ loglik, unsigned long long* __restrict__ nerr)
 {
   __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
   __shared__ double t_b[kEmitTasks];   // max (ratio route) or y
   __shared__ double t_r[kEmitTasks];   // min/max
+  __shared__ uint32_t t_i[kEmitTasks]; // where the task's tabulated terms are: index into tab_gl / tab_lg; bit 31: x is the
+                                       // larger argument; 0xffffffff: not tabulated
   __shared__ int n_front, n_back;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -194,12 +227,17 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       basef = __shfl(basef, 0, 64);
       baseb = __shfl(baseb, 0, 64);
       int sl = empty ? -2 : -1;
+      // the gather itself is done by whichever thread evaluates the task: issued at the top of the route, its
+      // result is needed ~100 instructions later, so the latency hides behind the task's own arithmetic
+      const bool tabbed = (unsigned)obs < (unsigned)kEmitTab && pos;
+      uint32_t ti = tabbed ? (uint32_t)(((int64_t)st * kEmitTab + obs) * S + s) : 0xffffffffu;
       if (front) {
         sl = basef + __popcll(mf & below);
-        t_a[sl] = mn; t_b[sl] = mx; t_r[sl] = rat;
+        if (tabbed && !(x < y)) ti |= 0x80000000u;   // x is the larger argument (x == y: its Gamma* serves as Gamma*(mx))
+        t_a[sl] = mn; t_b[sl] = mx; t_r[sl] = rat; t_i[sl] = ti;
       } else if (back) {
         sl = kEmitTasks - 1 - (baseb + __popcll(mb & below));
-        t_a[sl] = x; t_b[sl] = y; t_r[sl] = rat;
+        t_a[sl] = x; t_b[sl] = y; t_r[sl] = rat; t_i[sl] = ti;
       }
       slot[k * 3 + st] = sl;
     }
@@ -211,11 +249,17 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   for (int r = 0; r < kEmitCells * 3; ++r) {
     const int sl = r * kEmitBlock + tid;
     if (sl < nf) {
-      t_a[sl] = edsf::lnbeta_ratio(t_a[sl], t_b[sl], t_r[sl]);
+      const uint32_t ti = t_i[sl];
+      double2 gl = make_double2(ed_pm_nan(), ed_pm_nan());
+      if (ti != 0xffffffffu) gl = tab_gl[ti & 0x7fffffffu];
+      if (ti & 0x80000000u) gl.x = -gl.x;
+      t_a[sl] = edsf::lnbeta_ratio_pre(t_a[sl], t_b[sl], t_r[sl], gl.x, gl.y);
     } else if (sl >= kEmitTasks - nb) {
       const double x = t_a[sl], y = t_b[sl];
+      const uint32_t ti = t_i[sl];
+      const double lgx = (ti != 0xffffffffu) ? tab_lg[ti] : ed_pm_nan();
       int flag = 0;
-      t_a[sl] = (x > 0.0 && y > 0.0) ? edsf::lnbeta_general(x, y) : edsf::lnbeta_cold(x, y, &flag);
+      t_a[sl] = (x > 0.0 && y > 0.0) ? edsf::lnbeta_general_pre(x, y, lgx) : edsf::lnbeta_cold(x, y, &flag);
       nflag += flag;
     }
   }
@@ -1389,6 +1433,8 @@ struct ed_batch {
   std::vector<hipEvent_t> job_ev;       // emissions of group g are complete
   std::vector<hipEvent_t> join_ev;      // Viterbi (+ trace-back) of group g is complete
   double* d_consts = nullptr;
+  double2* d_tab_gl = nullptr;   // [3][kEmitTab][S] (Gamma*(a1 + obs), log(a1 + obs))   (k_emit_tables)
+  double* d_tab_lg = nullptr;    // [3][kEmitTab][S] log Gamma(a1 + obs)
   int* d_cflags = nullptr;
   int32_t* d_counts = nullptr;
   int64_t* d_offsets = nullptr;
@@ -1686,6 +1732,8 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   A((void**)&b->d_ent, (size_t)(plan->n_words / 16 + C + 1) * S * 4);
   A((void**)&b->d_last, (size_t)std::max<int64_t>(C, 1) * S);
   A((void**)&b->d_consts, (size_t)9 * S * 8);
+  A((void**)&b->d_tab_gl, (size_t)3 * kEmitTab * S * 16);
+  A((void**)&b->d_tab_lg, (size_t)3 * kEmitTab * S * 8);
   A((void**)&b->d_cflags, (size_t)3 * S * 4);
   A((void**)&b->d_counts, (size_t)S * std::max<int64_t>(C, 1) * 4);
   A((void**)&b->d_offsets, (size_t)S * std::max<int64_t>(C, 1) * 8);
@@ -1813,7 +1861,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -1850,9 +1898,13 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 8, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  if (bins == 0)
+  if (bins == 0) {
     hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
                        b->d_consts, b->d_cflags);
+    if (!b->fused)
+      hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S,
+                         b->d_tab_gl, b->d_tab_lg);
+  }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int64_t cells = E * S;
   if (b->fused) {
@@ -1890,10 +1942,11 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
                            d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S, b->d_loglik, b->d_nerr);
       if (head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
-                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_loglik, b->d_nerr);
+                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr);
       if (nblk - head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
-                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, (uint32_t)((S + 63) / 64), b->d_loglik, b->d_nerr);
+                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik,
+                           b->d_nerr);
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
       hipStream_t side = b->sides[g % b->sides.size()];
       HIP_TRY(hipStreamWaitEvent(side, b->job_ev[g], 0));
