@@ -304,3 +304,29 @@ def test_batch_cells_without_reads_and_error_count(edlib, oracle):
         if s not in (4,):
             assert np.all(ll[dead[:, s], :, s] == 0.0) and not np.any(np.signbit(ll[dead[:, s], :, s]))
     assert nerr == exp_err and exp_err > 0
+
+
+@pytest.mark.parametrize("depth,swap", [(3000.0, False), (40.0, True), (900.0, True)])
+def test_batch_parity_outside_the_tabulated_range(edlib, oracle, depth, swap):
+    """The emission kernel gathers the terms that depend on the test count alone from per-sample tables
+    (observed < 1024, x the smaller argument).  Counts beyond the tables, and test counts LARGER than the reference's
+    (x the larger argument, general route common), must give the checker's bits as well."""
+    from exomedepth_amd import synth
+    E, S, C = 2500, 5, 3
+    chrom_off, start, end = synth.exon_design(E, C, 77)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 77, n_segments=2, mean_depth=depth)
+    if swap:
+        test, ref = ref.copy(), test.copy()
+        p = 1.0 - p
+    if depth > 500:
+        assert test.max() >= 1024          # some cells lie beyond the tables
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    batch.run(test, ref, phi, p)
+    ll, path = batch.loglik(), batch.path()
+    batch.close(); plan.close()
+    for s in range(S):
+        exp_ll, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.PORTABLE)
+        assert np.array_equal(bits(ll[:, :, s]), bits(exp_ll)), "sample %d" % s
+        exp_path, _ = oracle.callcnvs(exp_ll, chrom_off, start, end)
+        assert np.array_equal(path[:, s].astype(np.int8), exp_path)
