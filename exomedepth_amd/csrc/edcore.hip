@@ -1938,8 +1938,13 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       const int64_t blk0 = b->seg[3 * j0], nblk = (bins > 0) ? 0 : b->seg[3 * j1] - blk0;
       const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
       if (bins > 0 && g == 0)   // one launch over every cell; the Viterbi groups follow it
-        hipLaunchKernelGGL(k_emit_bins, dim3((unsigned)((cells + kEmitBlock - 1) / kEmitBlock)), dim3(kEmitBlock), 0, st, d_test,
-                           d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S, b->d_loglik, b->d_nerr);
+      {
+        const int64_t eblk = (E + kEmitBlock / 64 - 1) / (kEmitBlock / 64);   // 4 exons x 64 samples per workgroup
+        hipLaunchKernelGGL(k_emit_bins, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535),
+                                             (unsigned)((eblk + 65534) / 65535)),
+                           dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S, b->d_loglik,
+                           b->d_nerr);
+      }
       if (head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
                            b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr);
