@@ -69,6 +69,7 @@ namespace {
 
 constexpr int kEmitBlock = 256;
 constexpr int kEmitTab = 1024;   // test counts covered by the per-sample tables (k_emit_tables)
+constexpr uint32_t kEmitRun = 256;   // exon blocks an XCD spends on one sample block before taking up the next (k_emit_batch)
 constexpr int kWave = 64;
 
 // myprob's shape parameters for one state (src/CNV_estimate.cpp:45-46)
@@ -179,8 +180,23 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   int si = 0;
   while (si + 1 < nseg && seg[3 * (si + 1)] <= blk) ++si;
   const uint32_t local = (uint32_t)(blk - seg[3 * si]);
-  const uint32_t eb = local / nsb, sb = local - eb * nsb;
   const int64_t e_end = seg[3 * si + 2];
+  uint32_t eb, sb;
+  if (nsb >= 8) {
+    // XCD-aware numbering (workgroup i runs on XCD i % 8; every segment starts at a multiple of 8): XCD x works on
+    // sample block x + 8 r only, and on ONE r at a time -- kEmitRun exon blocks of round r, then of round r + 1,
+    // ... -- so that the tables of one sample block (~2.3 MB of hot lines) are what its L2 holds.  Workgroups
+    // whose (exon block, sample block) falls outside the segment exit at once.
+    const uint32_t nsg = (nsb + 7) / 8, per_super = kEmitRun * 8 * nsg;
+    const uint32_t sup = local / per_super, idx = local - sup * per_super;
+    const uint32_t r = idx / (kEmitRun * 8), rem = idx % (kEmitRun * 8);
+    eb = sup * kEmitRun + rem / 8;
+    sb = (rem % 8) + 8 * r;
+    if (sb >= nsb || seg[3 * si + 1] + (int64_t)eb * kEmitRows >= e_end) return;   // uniform: before any barrier
+  } else {
+    eb = local / nsb;
+    sb = local - eb * nsb;
+  }
   const int64_t e_first = seg[3 * si + 1] + (int64_t)eb * kEmitRows + (tid >> 6);
   const int64_t s = (int64_t)sb * 64 + lane;
   int slot[kEmitCells * 3];
@@ -193,8 +209,9 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
     int32_t obs = 0, tot = 0;
     if (live) {
       const int64_t cell = e * S + s;
-      obs = test[cell];
-      tot = obs + ref[cell];   // as.integer(reference + test), R/class_definition.R:187
+      // streamed once: keep them (and the likelihood rows below) from evicting the tables out of L2
+      obs = __builtin_nontemporal_load(&test[cell]);
+      tot = obs + __builtin_nontemporal_load(&ref[cell]);   // as.integer(reference + test), R/class_definition.R:187
     }
     // A cell without reads: a1 + 0 and (a2 + 0) - 0 are a1 and a2 themselves, so the reference's second log-Beta
     // call repeats the per-sample one bit for bit (same value, same GSL error) -- no task, the result is c - c
@@ -274,7 +291,7 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
         const double c = consts[(st * 3 + 2) * S + s];
         const int sl = slot[k * 3 + st];
         const double v = t_a[sl < 0 ? 0 : sl];
-        loglik[(e * 3 + st) * S + s] = (sl == -2 ? c : v) - c;
+        __builtin_nontemporal_store((sl == -2 ? c : v) - c, &loglik[(e * 3 + st) * S + s]);
       }
     }
   }
@@ -1844,7 +1861,10 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
       const int c = jb[0];
       const int64_t eb = plan->chrom_off[c], ee = plan->chrom_off[c + 1];
       b->seg.push_back(blk); b->seg.push_back(eb); b->seg.push_back(ee);
-      blk += ((ee - eb + kEmitRows - 1) / kEmitRows) * ((S + 63) / 64);
+      {
+        const int64_t neb = (ee - eb + kEmitRows - 1) / kEmitRows, nsb = (S + 63) / 64;
+        blk += (nsb >= 8) ? ((neb + kEmitRun - 1) / kEmitRun) * (int64_t)kEmitRun * 8 * ((nsb + 7) / 8) : neb * nsb;
+      }
     }
     b->seg.push_back(blk); b->seg.push_back(0); b->seg.push_back(0);
     HIP_TRY(hipMalloc((void**)&b->d_seg, b->seg.size() * 8));
