@@ -104,6 +104,17 @@ ED_PM_FN double ed_pexp(double x)
 {
   const double c[ED_PM_EXP_NC] = ED_PM_EXP_COEFFS;
   if (x != x) return x;
+  if (x > -0x1p-5 && x < 0x1p-5) {
+    /* short series (the one case the hot path has: exp of a Stirling tail, |x| < 0.0084): e^x = 1 + (x + x^2 Q),
+     * Q = 1/2 + x/6 + ... + x^5/5040; the first dropped term, x^8/40320, is below 2.3e-17 */
+    double q = 1.0 / 5040.0;
+    q = ed_pm_fma_k(q, x, 1.0 / 720.0);
+    q = ed_pm_fma_k(q, x, 1.0 / 120.0);
+    q = ed_pm_fma_k(q, x, 1.0 / 24.0);
+    q = ed_pm_fma_k(q, x, 1.0 / 6.0);
+    q = ed_pm_fma_k(q, x, 0.5);
+    return 1.0 + ed_pm_fma(x * x, q, x);
+  }
   if (x > 0x1.62e42fefa39efp+9) return ed_pm_inf();     /* > log(DBL_MAX) */
   if (x < -0x1.74910d52d3051p+9) return 0.0;            /* < log(2^-1075) */
   const double t = x * ED_PM_INV_LN2;

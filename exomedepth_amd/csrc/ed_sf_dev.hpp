@@ -81,14 +81,15 @@ __device__ __forceinline__ double fdiv(double a, double b)
   return __builtin_fma(rem, r, q);
 }
 
-// ed_pexp(x) for |x| < ln2/2 only: there the argument reduction of ed_pexp is the identity (k = 0,
-// r = x exactly, both scale factors 2^0), so skipping it yields the same bits.
+// ed_pexp(x) for |x| < 2^-5 only: the short-series branch of ed_pexp, without its range tests.
 __device__ __forceinline__ double pexp_small(double x)
 {
-  const double c[ED_PM_EXP_NC] = ED_PM_EXP_COEFFS;
-  double q = c[ED_PM_EXP_NC - 1];
-#pragma unroll
-  for (int i = ED_PM_EXP_NC - 2; i >= 0; --i) q = ed_pm_fma_k(q, x, c[i]);
+  double q = 1.0 / 5040.0;
+  q = ed_pm_fma_k(q, x, 1.0 / 720.0);
+  q = ed_pm_fma_k(q, x, 1.0 / 120.0);
+  q = ed_pm_fma_k(q, x, 1.0 / 24.0);
+  q = ed_pm_fma_k(q, x, 1.0 / 6.0);
+  q = ed_pm_fma_k(q, x, 0.5);
   return 1.0 + ed_pm_fma(x * x, q, x);
 }
 

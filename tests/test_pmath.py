@@ -30,7 +30,9 @@ def test_plog(oracle):
 
 def test_pexp(oracle):
     rng = np.random.default_rng(1)
-    x = np.concatenate([rng.uniform(-700, 700, 2000), rng.uniform(-1, 1, 1500), rng.uniform(0, 0.01, 800)])
+    x = np.concatenate([rng.uniform(-700, 700, 2000), rng.uniform(-1, 1, 1500), rng.uniform(0, 0.01, 800),
+                        rng.uniform(-2.0 ** -5, 2.0 ** -5, 3000),            # the short-series branch and its seam
+                        np.array([2.0 ** -5, -2.0 ** -5, np.nextafter(2.0 ** -5, 0), np.nextafter(-2.0 ** -5, 0), 1e-300, -1e-20])])
     assert _max_ulp(mp.exp, x, oracle.pexp(x)) < 0.9
     sp = oracle.pexp(np.array([-746.0, 710.0, np.nan, 0.0, -745.0]))
     assert sp[0] == 0.0 and sp[1] == np.inf and np.isnan(sp[2]) and sp[3] == 1.0 and sp[4] == 5e-324
