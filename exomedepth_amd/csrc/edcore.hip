@@ -1094,15 +1094,21 @@ __device__ __forceinline__ void fit_newton_step(const double (&tot)[kFitQ], doub
   // Chain rule:  d/dpsi = -th d/dlambda  =>  g_s = -th g_l,  h_es = -th h_el,  h_ss = th^2 (h_ll + g_l).
   const double psi = 1.0 / th;
   double de, ds;
+  bool newton;   // a genuine Newton step (locally concave model): only such a step may declare convergence
   if (psi >= 5e-5) {
     const double det = h_ee * h_ll - h_el * h_el;
     double dl;
-    if (h_ee < 0.0 && det > 0.0) {
+    newton = (h_ee < 0.0 && det > 0.0);
+    if (newton) {
       de = -(h_ll * g_e - h_el * g_l) / det;
       dl = -(h_ee * g_l - h_el * g_e) / det;
-    } else {   // not locally concave: scaled gradient step
+    } else {
+      // Not locally concave (typically psi far below its optimum, where the likelihood is convex and nearly flat
+      // in lambda): move uphill in lambda by the Newton magnitude but at most 0.5 -- a factor 1.65 in psi -- per
+      // iteration.  (A step scaled by the whole Hessian crawls: 1.4 % per iteration on the case kept in
+      // tests/golden/fit_slow_start_case.npz.)
       de = g_e / (fabs(h_ee) + 1e-300);
-      dl = g_l / (fabs(h_ll) + fabs(h_el) + 1e-300);
+      dl = (g_l > 0.0 ? 1.0 : -1.0) * fmin(0.5, fabs(g_l) / (fabs(h_ll) + 1e-300));
     }
     dl = fmin(fmax(dl, -1.0), 1.0);
     ds = psi * (ed_pexp(-dl) - 1.0);
@@ -1111,12 +1117,13 @@ __device__ __forceinline__ void fit_newton_step(const double (&tot)[kFitQ], doub
     const double h_es = -th * h_el;
     const double h_ss = th * th * (h_ll + g_l);
     const double det = h_ee * h_ss - h_es * h_es;
-    if (h_ee < 0.0 && det > 0.0) {
+    newton = (h_ee < 0.0 && det > 0.0);
+    if (newton) {
       de = -(h_ss * g_e - h_es * g_s) / det;
       ds = -(h_ee * g_s - h_es * g_e) / det;
     } else {
       de = g_e / (fabs(h_ee) + 1e-300);
-      ds = g_s / (fabs(h_ss) + fabs(h_es) + 1e-300);
+      ds = (g_s > 0.0 ? 1.0 : -1.0) * fmin(0.5 * psi, fabs(g_s) / (fabs(h_ss) + 1e-300));
     }
   }
   de = fmin(fmax(de, -1.0), 1.0);
@@ -1132,7 +1139,7 @@ __device__ __forceinline__ void fit_newton_step(const double (&tot)[kFitQ], doub
   // error left after applying it is of order tol^2, far below the 1e-8 the fit is held to -- no
   // confirming pass is needed.  A sample pinned at the lower bound of psi has also converged.
   const bool at_floor = (npsi <= 1e-6 && psi <= 1.0000001e-6);
-  if (final_pass && ((fabs(de) < tol && fabs(npsi - psi) < tol * psi) || at_floor)) done_v = 1;
+  if (final_pass && ((newton && fabs(de) < tol && fabs(npsi - psi) < tol * psi) || at_floor)) done_v = 1;
 }
 
 __global__ void __launch_bounds__(kWave * kRedY)
@@ -1309,33 +1316,46 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
       const double th = ed_pexp(sh_lam[lane]);
       const double p = 1.0 / (1.0 + ed_pexp(-sh_eta[lane]));
       const double a = th * p, b = th * (1.0 - p);
+      // The sums are formed from DIFFERENCES psi(a + v) - psi(a) = ln((a + v)/a) + (rest(a + v) - rest(a)) (and the
+      // same for b, a + b and for psi'): the constant terms of the gradient are folded in bin by bin instead of being
+      // subtracted from a sum ~1/phi times larger at the end, which cost 1/phi in relative accuracy (seen as 1e-5
+      // on phi at phi = 5e-5 with the plain sums).
+      double xa, ra, qa, xb, rb, qb, xt, rt, qt;
+      edfit::digamma_trigamma_nolog(a, xa, ra, qa);
+      edfit::digamma_trigamma_nolog(b, xb, rb, qb);
+      edfit::digamma_trigamma_nolog(th, xt, rt, qt);
+      const double ixa = edfit::frcp(xa), ixb = edfit::frcp(xb), ixt = edfit::frcp(xt);
       for (int v = y; v < kHistKy; v += kHnY) {
         const uint32_t c = hist[(int64_t)v * S + sc] + hist[((int64_t)kHistK + v) * S + sc];
         if (c) {
-          double ps, p1;
-          edfit::digamma_trigamma(a + (double)v, ps, p1);
-          acc[0] += (double)c * ps; acc[2] += (double)c * p1;
+          double x1, r1, q1;
+          edfit::digamma_trigamma_nolog(a + (double)v, x1, r1, q1);
+          acc[0] += (double)c * (edfit::flog(x1 * ixa) + (r1 - ra));
+          acc[2] += (double)c * (q1 - qa);
         }
       }
       for (int v = y; v < kHistKr; v += kHnY) {
         const uint32_t c = hist[(int64_t)(kHistKy + v) * S + sc] + hist[((int64_t)kHistK + kHistKy + v) * S + sc];
         if (c) {
-          double ps, p1;
-          edfit::digamma_trigamma(b + (double)v, ps, p1);
-          acc[1] += (double)c * ps; acc[4] += (double)c * p1;
+          double x1, r1, q1;
+          edfit::digamma_trigamma_nolog(b + (double)v, x1, r1, q1);
+          acc[1] += (double)c * (edfit::flog(x1 * ixb) + (r1 - rb));
+          acc[4] += (double)c * (q1 - qb);
         }
       }
       for (int v = y; v < kHistKn; v += kHnY) {
         const uint32_t c = hist[(int64_t)(kHistKy + kHistKr + v) * S + sc] + hist[((int64_t)kHistK + kHistKy + kHistKr + v) * S + sc];
         if (c) {
-          double ps, p1;
-          edfit::digamma_trigamma(th + (double)v, ps, p1);
+          double x1, r1, q1;
+          edfit::digamma_trigamma_nolog(th + (double)v, x1, r1, q1);
           const double cd = (double)c;
-          acc[0] -= cd * ps; acc[1] -= cd * ps;
-          acc[2] -= cd * p1; acc[3] -= cd * p1; acc[4] -= cd * p1;
-          acc[5] += cd;
+          const double dps = cd * (edfit::flog(x1 * ixt) + (r1 - rt)), dq = cd * (q1 - qt);
+          acc[0] -= dps; acc[1] -= dps;
+          acc[2] -= dq; acc[3] -= dq; acc[4] -= dq;
         }
       }
+      // cells beyond the bins: evaluated whole, minus the same constant terms
+      const double ca = edfit::flog(xa * ixt) + (ra - rt), cb = edfit::flog(xb * ixt) + (rb - rt);
 #pragma unroll
       for (int k = 0; k < kHistGroups / kHnY; ++k) {
         const int64_t base = (int64_t)(y + k * kHnY) * cap;
@@ -1343,10 +1363,11 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
           const int yy = ov_y[(base + i) * S + sc], rr = ov_r[(base + i) * S + sc];
           edfit::Acc c = {0, 0, 0, 0, 0};
           edfit::accumulate_cell(c, a, b, th, yy, yy + rr);
-          acc[0] += c.ga; acc[1] += c.gb; acc[2] += c.haa; acc[3] += c.hab; acc[4] += c.hbb; acc[5] += 1.0;
+          acc[0] += c.ga - ca; acc[1] += c.gb - cb; acc[2] += c.haa - (qa - qt); acc[3] += c.hab + qt; acc[4] += c.hbb - (qb - qt);
         }
       }
     }
+    // acc[5] (the cell count that scales the constant terms in fit_newton_step) stays 0: they are already in
 #pragma unroll
     for (int q = 0; q < kFitQ; ++q) lds[q][y][lane] = acc[q];
     __syncthreads();
@@ -2082,7 +2103,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     hipLaunchKernelGGL(k_fit_hist, dim3((unsigned)((((S + kHistSamples - 1) / kHistSamples * kHistHalves + 7) / 8) * 8)), dim3(kHistBlock), 0, st, d_test, d_ref,
                        rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap);
     hipLaunchKernelGGL(k_fit_hnewton, dim3((unsigned)((S + kHnS - 1) / kHnS)), dim3(kHnS, kHnY), 0, st, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap, S,
-                       w.eta, w.lam, w.done, 40, 1e-6);
+                       w.eta, w.lam, w.done, 100, 1e-9);   // iterations are cheap here: converge tightly
   }
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
   const int coarse = (E >= 8192 && !use_hist) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
@@ -2176,11 +2197,28 @@ static int batch_ready(ed_batch* b)
   return ED_OK;
 }
 
+// The call table is sized by a heuristic when the batch is created; a run that produced more calls than that (up
+// to one per exon is possible) gets a table of the right size and the fill kernel is run again -- the records
+// are a pure function of the packed path.
 ED_EXPORT int ed_batch_n_calls(ed_batch* b, int64_t* n_calls)
 {
   if (int rc = batch_ready(b)) return rc;
   if (!n_calls) return ed_fail(ED_ERR_INVALID, "NULL output");
   HIP_TRY(hipMemcpy(n_calls, b->d_total, 8, hipMemcpyDeviceToHost));
+  if (*n_calls > b->calls_cap) {
+    const ed_plan* p = b->plan;
+    const int64_t cap = *n_calls + *n_calls / 8 + 1024;
+    ed_call* fresh = nullptr;
+    if (hipMalloc((void**)&fresh, (size_t)cap * sizeof(ed_call)) != hipSuccess)
+      return ed_fail(ED_ERR_NOMEM, "call table: cannot allocate %lld records", (long long)cap);
+    (void)hipFree(b->d_calls);
+    b->d_calls = fresh;
+    b->calls_cap = cap;
+    hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((b->S + kWave - 1) / kWave), (unsigned)p->C), dim3(kWave), 0, b->stream,
+                       b->d_ppath, p->d_chrom_off, p->d_tile_off, b->S, p->C, b->d_offsets, b->d_counts, b->d_calls, b->calls_cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
   return ED_OK;
 }
 
@@ -2197,9 +2235,7 @@ ED_EXPORT int ed_batch_n_gsl_errors(ed_batch* b, int64_t* n_events)
 ED_EXPORT int ed_batch_copy_calls(ed_batch* b, ed_call* host_calls, int64_t cap)
 {
   int64_t n = 0;
-  if (int rc = ed_batch_n_calls(b, &n)) return rc;
-  if (n > b->calls_cap)
-    return ed_fail(ED_ERR_STATE, "call table overflow: %lld calls, capacity %lld", (long long)n, (long long)b->calls_cap);
+  if (int rc = ed_batch_n_calls(b, &n)) return rc;   // (grows the table if the run needed more records)
   const int64_t k = std::min(n, cap);
   if (k > 0) {
     if (!host_calls) return ed_fail(ED_ERR_INVALID, "NULL output");
@@ -2211,9 +2247,7 @@ ED_EXPORT int ed_batch_copy_calls(ed_batch* b, ed_call* host_calls, int64_t cap)
 ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int64_t cap)
 {
   int64_t n = 0;
-  if (int rc = ed_batch_n_calls(b, &n)) return rc;
-  if (n > b->calls_cap)
-    return ed_fail(ED_ERR_STATE, "call table overflow: %lld calls, capacity %lld", (long long)n, (long long)b->calls_cap);
+  if (int rc = ed_batch_n_calls(b, &n)) return rc;   // (grows the table if the run needed more records)
   const int64_t k = std::min(n, cap);
   if (k <= 0) return ED_OK;
   if (!host_info) return ed_fail(ED_ERR_INVALID, "NULL output");

@@ -176,7 +176,9 @@ int ed_batch_n_emit_launches(const ed_batch* batch);
 /* device-resident results of the last ed_batch_run */
 const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples] */
 const uint8_t* ed_batch_path(const ed_batch* batch);   /* [n_exons][n_samples]    */
-const ed_call* ed_batch_calls(const ed_batch* batch);  /* device array, length ed_batch_n_calls() */
+const ed_call* ed_batch_calls(const ed_batch* batch);  /* device array, length ed_batch_n_calls(); call that first: it
+                                                         * also re-sizes the table if the run produced more calls than
+                                                         * the batch had provisioned */
 /* synchronises the stream of the last run */
 int ed_batch_n_calls(ed_batch* batch, int64_t* n_calls);
 int ed_batch_n_gsl_errors(ed_batch* batch, int64_t* n_events);

@@ -331,3 +331,28 @@ def test_batch_parity_outside_the_tabulated_range(edlib, oracle, depth, swap):
         assert np.array_equal(bits(ll[:, :, s]), bits(exp_ll)), "sample %d" % s
         exp_path, _ = oracle.callcnvs(exp_ll, chrom_off, start, end)
         assert np.array_equal(path[:, s].astype(np.int8), exp_path)
+
+
+def test_call_table_grows_on_demand(edlib, oracle):
+    """Every exon its own call (deletion / duplication alternating): more records than the batch provisioned when it
+    was created; the table must be re-sized and filled again, identical to the checker's."""
+    E, S = 40, 8
+    chrom_off = np.array([0, E], dtype=np.int32)
+    start = (np.arange(E) * 10_000 + 1000).astype(np.int32)
+    end = start + 200
+    ref = np.full((E, S), 9000, dtype=np.int32)
+    test = np.where((np.arange(E) % 2 == 0)[:, None], 500, 1500).astype(np.int32) * np.ones((1, S), dtype=np.int32)
+    phi = np.full(S, 1e-4); p = np.full(S, 0.1)
+    plan = edlib.Plan(chrom_off, start, end, 0.3, 2000.0)
+    batch = edlib.Batch(plan, S)
+    batch.run(test, ref, phi, p)
+    calls, ll = batch.calls(), batch.loglik()
+    info = batch.call_info()
+    batch.close(); plan.close()
+    assert len(calls) > E * S // 2 and len(info) == len(calls)
+    for s in range(S):
+        exp_path, exp_calls = oracle.callcnvs(ll[:, :, s], chrom_off, start, end, 0.3, 2000.0)
+        mine = calls[calls["sample"] == s]
+        assert len(mine) == len(exp_calls) == E
+        assert np.array_equal(mine["start_exon"] + 1, exp_calls[:, 0].astype(np.int64))
+        assert np.array_equal(mine["type"], exp_calls[:, 2].astype(np.int64))
