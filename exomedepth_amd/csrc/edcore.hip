@@ -1931,6 +1931,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
 {
   if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_run: NULL argument");
   if (bins > 0 && b->fused) return ed_fail(ED_ERR_STATE, "ed_batch_run_bins: not available in fused mode");
+  HIP_TRY(hipSetDevice(b->plan->device));   // the caller's thread may have another device current (one process, many GPUs)
   hipStream_t st = (hipStream_t)stream_;
   const ed_plan* p = b->plan;
   const int64_t E = p->E, S = b->S;
@@ -2130,6 +2131,7 @@ ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int3
   const int64_t E = b->plan->E, S = b->S;
   if (E <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_fit: no exons");
   if (by < 1) return ed_fail(ED_ERR_INVALID, "ed_batch_fit_subset: row step %lld < 1 (subset.for.speed larger than the number of exons?)", (long long)by);
+  HIP_TRY(hipSetDevice(b->plan->device));
   if (!b->fitw) {
     b->fitw = new (std::nothrow) FitWork;
     if (!b->fitw) return ed_fail(ED_ERR_NOMEM, "out of host memory");
@@ -2193,6 +2195,7 @@ static int batch_ready(ed_batch* b)
 {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (!b->ran) return ed_fail(ED_ERR_STATE, "no ed_batch_run has been issued on this batch");
+  HIP_TRY(hipSetDevice(b->plan->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   return ED_OK;
 }
