@@ -1752,14 +1752,18 @@ ED_EXPORT int64_t ed_plan_n_exons(const ed_plan* p) { return p ? p->E : 0; }
 ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples)
 {
   if (!batch || !plan || n_samples <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_create: bad arguments");
+  // 32-bit lane offsets (Viterbi rows, table entries): 3 * kEmitTab * n_samples must stay below 2^31
+  if (n_samples > 500000)
+    return ed_fail(ED_ERR_INVALID, "ed_batch_create: %lld samples in one batch; at most 500000 (split the cohort into batches)",
+                   (long long)n_samples);
   if (int rc = require_device()) return rc;
   HIP_TRY(hipSetDevice(plan->device));
   ed_batch* b = new (std::nothrow) ed_batch;
   if (!b) return ed_fail(ED_ERR_NOMEM, "out of host memory");
   b->plan = plan; b->S = n_samples;
   const int64_t E = plan->E, S = n_samples, C = plan->C;
-  // capacity of the call table: generous for real data (a few hundred calls per sample), bounded so a
-  // pathological input cannot exhaust HBM; ed_batch_n_calls reports the true total either way.
+  // capacity of the call table: generous for real data (a few hundred calls per sample); a run that needs more
+  // gets a larger table from ed_batch_n_calls (the fill kernel is run again).
   b->calls_cap = std::min<int64_t>(std::max<int64_t>(1 << 20, 512 * S), std::max<int64_t>(E * S / 2, 1));
   bool ok = true;
   auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes ? bytes : 1) != hipSuccess) ok = false; };
