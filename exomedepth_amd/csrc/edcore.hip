@@ -1279,7 +1279,8 @@ static_assert(kHistGroups % kHnY == 0, "every strand owns whole overflow regions
 __global__ void __launch_bounds__(kHnS * kHnY)
 k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_y, const int32_t* __restrict__ ov_r,
               const int32_t* __restrict__ ovn, int64_t cap, int64_t S, double* __restrict__ eta, double* __restrict__ lam,
-              int* __restrict__ done, int max_iter, double tol)
+              int* __restrict__ done, int max_iter, double tol, const int32_t* __restrict__ test,
+              const int32_t* __restrict__ ref, int64_t rs, int64_t E)
 {
   __shared__ double lds[kFitQ][kHnY][kHnS];
   __shared__ double sh_eta[kHnS], sh_lam[kHnS];
@@ -1299,11 +1300,11 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
   }
   if (over) atomicOr(&sh_over[lane], 1);
   __syncthreads();
-  const bool fits = !sh_over[lane];            // otherwise the per-cell kernels take this sample
+  const bool fits = !sh_over[lane];            // otherwise (an overflow region ran out) the sample is summed cell by cell
   if (y == 0) {
     sh_eta[lane] = eta[sc];
     sh_lam[lane] = lam[sc];
-    sh_done[lane] = (live && fits) ? done[sc] : 1;
+    sh_done[lane] = live ? done[sc] : 1;
   }
   __syncthreads();
   for (int it = 0; it < max_iter; ++it) {
@@ -1312,7 +1313,20 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
     double acc[kFitQ];
 #pragma unroll
     for (int q = 0; q < kFitQ; ++q) acc[q] = 0.0;
-    if (!dn) {
+    if (!dn && !fits) {
+      // rare: the plain per-cell sums (raw psi values, the cell count in acc[5] lets fit_newton_step subtract the
+      // constant terms), the strands sharing the rows
+      const double th = ed_pexp(sh_lam[lane]);
+      const double p = 1.0 / (1.0 + ed_pexp(-sh_eta[lane]));
+      const double a = th * p, b = th * (1.0 - p);
+      edfit::Acc c = {0, 0, 0, 0, 0};
+      double n_cells = 0.0;
+      for (int64_t e = y; e < E; e += kHnY) {
+        const int yy = test[e * rs + sc], rr = ref[e * rs + sc];
+        if (yy + rr > 0) { edfit::accumulate_cell(c, a, b, th, yy, yy + rr); n_cells += 1.0; }
+      }
+      acc[0] = c.ga; acc[1] = c.gb; acc[2] = c.haa; acc[3] = c.hab; acc[4] = c.hbb; acc[5] = n_cells;
+    } else if (!dn) {
       const double th = ed_pexp(sh_lam[lane]);
       const double p = 1.0 / (1.0 + ed_pexp(-sh_eta[lane]));
       const double a = th * p, b = th * (1.0 - p);
@@ -1389,7 +1403,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
     }
     __syncthreads();
   }
-  if (y == 0 && live && fits) {
+  if (y == 0 && live) {
     eta[s] = sh_eta[lane];
     lam[s] = sh_lam[lane];
     done[s] = sh_done[lane];
@@ -2089,8 +2103,8 @@ static void fitwork_free(FitWork* w)
 }
 
 // Fit S columns: column s has test counts test[e*trs + s*tcs] and reference counts ref[e*rrs + s], e < E.
-// use_hist: build count histograms once and iterate on them (needs one test column per sample laid out like the
-// reference counts: tcs == 1, trs == rrs); the per-cell passes that follow then only serve samples it left over.
+// use_hist: build count histograms once and iterate on them in one launch (needs one test column per sample laid
+// out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
                        int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, bool use_hist = false)
 {
@@ -2108,10 +2122,14 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     hipLaunchKernelGGL(k_fit_hist, dim3((unsigned)((((S + kHistSamples - 1) / kHistSamples * kHistHalves + 7) / 8) * 8)), dim3(kHistBlock), 0, st, d_test, d_ref,
                        rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap);
     hipLaunchKernelGGL(k_fit_hnewton, dim3((unsigned)((S + kHnS - 1) / kHnS)), dim3(kHnS, kHnY), 0, st, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap, S,
-                       w.eta, w.lam, w.done, 100, 1e-9);   // iterations are cheap here: converge tightly
+                       w.eta, w.lam, w.done, 100, 1e-9,   // iterations are cheap here: converge tightly
+                       d_test, d_ref, rrs, E);
+    hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
+    HIP_TRY(hipGetLastError());
+    return ED_OK;
   }
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
-  const int coarse = (E >= 8192 && !use_hist) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
+  const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   for (int it = 0; it < coarse; ++it) {
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 16, w.eta, w.lam, w.done, w.partial);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 0);

@@ -139,3 +139,10 @@ def test_fit_slow_start_case(edlib, oracle, hist):
     # a + b = 3 200 here: the digamma differences of the gradient cancel ~4 digits more than at phi ~ 5e-3, and the
     # binary64 digamma (5e-15 relative) shows: 1e-8 relative on phi observed, 1e-7 asserted
     assert np.all(np.abs(gphi - ophi) < 1e-7 * ophi) and np.all(np.abs(gexp - op) < FIT_REL_TOL * op)
+
+
+def test_fit_counts_beyond_the_histogram_range(edlib, oracle):
+    """Deep data: every reference count lies beyond the 4096 bins, the overflow regions run out, and the Newton
+    kernel sums those samples cell by cell (same launch).  A moderately deep case uses bins and overflow lists together."""
+    _fit_case(edlib, oracle, E=3000, S=6, seed=45, mean_depth=3000.0)
+    _fit_case(edlib, oracle, E=5000, S=5, seed=46, mean_depth=400.0)
