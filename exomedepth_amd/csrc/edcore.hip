@@ -772,33 +772,32 @@ k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chr
   const uint32_t* __restrict__ pp = ppath + word_off[c] * S + s;
   const int64_t nw = (m + kVitTile - 1) / kVitTile;   // unused high bits of the last word are zero
   constexpr int kW = 16;
-  int64_t start = -1;
-  int nexons = 0, prev = 0, k = 0;
-  auto step = [&](int cur, int64_t x) {
-    if (prev != cur) {
-      if (prev == 0) {
-        start = x;
-      } else {
-        const int64_t r = off + k;
-        if (r < cap) {
-          ed_call rec;
-          rec.sample = (int32_t)s;
-          rec.chrom = c;
-          rec.start_exon = (int32_t)(lo + start);
-          rec.end_exon = (int32_t)(lo + x - 1);
-          rec.type = prev;
-          rec.nexons = nexons;
-          calls[r] = rec;
-        }
-        ++k;
-        nexons = 0;
+  // Only the positions where the state CHANGES are visited (found with bit operations on the packed word): between
+  // two changes the summary loop of the reference does nothing but count, and `nexons` -- reset at every push,
+  // incremented on every non-zero exon -- is the length of the run that ends, x - run_begin.
+  int64_t start = -1, run_begin = 0;
+  int prev = 0, k = 0;
+  auto change = [&](int cur, int64_t x) {   // the state changes from prev to cur at exon x
+    if (prev == 0) {
+      start = x;
+    } else {
+      const int64_t r = off + k;
+      if (r < cap) {
+        ed_call rec;
+        rec.sample = (int32_t)s;
+        rec.chrom = c;
+        rec.start_exon = (int32_t)(lo + start);
+        rec.end_exon = (int32_t)(lo + x - 1);
+        rec.type = prev;
+        rec.nexons = (int32_t)(x - run_begin);
+        calls[r] = rec;
       }
+      ++k;
     }
-    if (cur != 0) ++nexons;
+    run_begin = x;
     prev = cur;
   };
-  uint32_t nxt[kW];   // the next kW words are requested before the current ones are walked (the loop is latency-bound:
-                      // nearly every word is all-normal and skipped)
+  uint32_t nxt[kW];   // the next kW words are requested before the current ones are walked
 #pragma unroll
   for (int t = 0; t < kW; ++t) nxt[t] = (t < nw) ? pp[(int64_t)t * S] : 0u;
   for (int64_t wb = 0; wb < nw && __any(k < todo); wb += kW) {
@@ -809,13 +808,18 @@ k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chr
     for (int t = 0; t < kW; ++t) nxt[t] = (wb + kW + t < nw) ? pp[(wb + kW + t) * S] : 0u;
 #pragma unroll
     for (int t = 0; t < kW; ++t) {
-      if ((w[t] | (uint32_t)prev) == 0) continue;
+      const uint32_t before = (w[t] << 2) | (uint32_t)prev;        // state of the exon before each position
+      const uint32_t diff = w[t] ^ before;
+      uint32_t mk = (diff | (diff >> 1)) & 0x55555555u;            // one bit per position whose state differs
       const int64_t x0 = (wb + t) * kVitTile;
-#pragma unroll
-      for (int q = 0; q < kVitTile; ++q) step((int)((w[t] >> (2 * q)) & 3), x0 + q);
+      while (mk) {
+        const int q = __builtin_ctz(mk) >> 1;
+        mk &= mk - 1;
+        change((int)((w[t] >> (2 * q)) & 3u), x0 + q);
+      }
     }
   }
-  if (prev != 0 && k < todo) step(0, m);   // the dummy last observation closes a run that reaches the end
+  if (prev != 0 && k < todo) change(0, m);   // the dummy last observation closes a run that reaches the end
 }
 
 // Decoration of the call table (R/class_definition.R:379-405): per call, BF = sum over its exons of
