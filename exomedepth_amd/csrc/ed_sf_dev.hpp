@@ -93,33 +93,20 @@ __device__ __forceinline__ double pexp_small(double x)
   return 1.0 + ed_pm_fma(x * x, q, x);
 }
 
-// ed_plog(x) for normal positive finite x, with the in-range division: same bits as ed_plog.
-__device__ __forceinline__ double plog_pos(double x)
+// ed_plog(x) for normal positive finite x: the core of the portable definition without its special cases.
+// LT: the log table staged in LDS by the calling kernel (NULL: the table in constant memory -- 64 lanes gathering
+// rows from it keep the texture addresser busy ~48 cycles per load, which cancelled the instruction savings of
+// the table-driven log in k_emit_batch until the table moved to LDS).
+__device__ __forceinline__ double plog_pos(double x, const double* LT = nullptr)
 {
-  const double c[ED_PM_LOG_NC] = ED_PM_LOG_COEFFS;
-  const uint64_t u = ed_pm_bits(x);
-  int k = (int)(u >> 52) - 1023;
-  double m = ed_pm_from_bits((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
-  if (m > ED_PM_SQRT2) { m = m * 0.5; k += 1; }
-  const double f = m - 1.0;
-  const double s = fdiv(f, 2.0 + f);
-  const double z = s * s;
-  double g = c[ED_PM_LOG_NC - 1];
-#pragma unroll
-  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma_k(g, z, c[i]);
-  const double R = z * g;
-  const double hfsq = (0.5 * f) * f;
-  const double dk = (double)k;
-  const double w = ed_pm_fma(s, hfsq + R, dk * ED_PM_LN2_LO);
-  const double v = f - (hfsq - w);
-  return ed_pm_fma(dk, ED_PM_LN2_HI, v);
+  return LT ? ed_plog_core_t(x, 0, LT) : ed_plog_core(x, 0);
 }
 
 // ed_plog with the fast path taken whenever x is a normal positive finite number (the cold generic
 // definition handles zero, subnormals, inf, NaN); same bits either way.
-__device__ __forceinline__ double plog_fast(double x)
+__device__ __forceinline__ double plog_fast(double x, const double* LT = nullptr)
 {
-  if (x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308) return plog_pos(x);
+  if (x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308) return plog_pos(x, LT);
   return ed_plog(x);
 }
 
@@ -141,7 +128,7 @@ __device__ __forceinline__ double clenshaw(const double* __restrict__ c, double 
 }
 
 // log Gamma(x), x >= 0.5 and outside the Pade windows: Lanczos gamma=7 (src/VP_gamma.c:735-756)
-__device__ __forceinline__ double lngamma_lanczos(double x)
+__device__ __forceinline__ double lngamma_lanczos(double x, const double* LT = nullptr)
 {
   x -= 1.0;
   if (x < 0x1p900) {   // every quotient below is in fdiv's range (x + k >= 0.5)
@@ -154,8 +141,8 @@ __device__ __forceinline__ double lngamma_lanczos(double x)
     Ag += fdiv(-0.13857109526572011689554707, x + 6.0);
     Ag += fdiv(9.984369578019570859563e-6, x + 7.0);
     Ag += fdiv(1.50563273514931155834e-7, x + 8.0);
-    const double term1 = (x + 0.5) * plog_pos(fdiv(x + 7.5, EDSF_M_E));
-    const double term2 = EDSF_LOGROOT2PI + plog_fast(Ag);
+    const double term1 = (x + 0.5) * plog_pos(fdiv(x + 7.5, EDSF_M_E), LT);
+    const double term2 = EDSF_LOGROOT2PI + plog_fast(Ag, LT);
     return term1 + (term2 - 7.0);
   }
   double Ag = 0.99999999999980993227684700473478;
@@ -214,11 +201,11 @@ __device__ __noinline__ double lngamma_below_half(double x, bool zform)
 }
 
 // log Gamma(x) for x > 0 with the reference's window selection (src/VP_gamma.c:1219-1242)
-__device__ __forceinline__ double lngamma_pos(double x, bool zform)
+__device__ __forceinline__ double lngamma_pos(double x, bool zform, const double* LT = nullptr)
 {
   if (fabs(x - 1.0) < 0.01) return lngamma_pade(x - 1.0, 0);
   if (fabs(x - 2.0) < 0.01) return lngamma_pade(x - 2.0, 1);
-  if (x >= 0.5) return lngamma_lanczos(x);
+  if (x >= 0.5) return lngamma_lanczos(x, LT);
   return lngamma_below_half(x, zform);
 }
 
@@ -318,27 +305,28 @@ __device__ __forceinline__ double lnbeta_ratio(double mn, double mx, double rat)
 // The same with Gamma*(mn) and log(mn) handed in (g > 0: g = Gamma*(mn), l = log(mn)), or with Gamma*(mx) handed in
 // (g < 0: -g = Gamma*(mx)), or with nothing known (g NaN).  Gamma* of a positive argument is positive, so the sign
 // is free to carry that bit.  The values must come from gammastar_pos / plog_fast themselves: same bits.
-__device__ __forceinline__ double lnbeta_ratio_pre(double mn, double mx, double rat, double g, double l)
+__device__ __forceinline__ double lnbeta_ratio_pre(double mn, double mx, double rat, double g, double l,
+                                                   const double* LT = nullptr)
 {
   const bool have_mn = g > 0.0;
   const double gsa = have_mn ? g : gammastar_pos(mn);
   const double gsb = (g < 0.0) ? -g : gammastar_pos(mx);
   const double gsxy = gammastar_pos(mn + mx);
   const double lnopr = log1plusx_ratio(rat);
-  const double lnpre = plog_fast((fdiv(gsa * gsb, gsxy) * EDSF_M_SQRT2) * EDSF_M_SQRTPI);
-  const double t1 = mn * plog_fast(rat);
-  const double t2 = 0.5 * (have_mn ? l : plog_fast(mn));
+  const double lnpre = plog_fast((fdiv(gsa * gsb, gsxy) * EDSF_M_SQRT2) * EDSF_M_SQRTPI, LT);
+  const double t1 = mn * plog_fast(rat, LT);
+  const double t2 = 0.5 * (have_mn ? l : plog_fast(mn, LT));
   const double t3 = ((mn + mx) - 0.5) * lnopr;
   return lnpre + ((t1 - t2) - t3);
 }
 
 // +inf arguments reach this route with rat = NaN; the arithmetic then yields NaN as the reference's does.
 // (lgx handed in, from lngamma_pos(x, false) itself; NaN = not known)
-__device__ __forceinline__ double lnbeta_general_pre(double x, double y, double lgx_in)
+__device__ __forceinline__ double lnbeta_general_pre(double x, double y, double lgx_in, const double* LT = nullptr)
 {
-  const double lgx = (lgx_in == lgx_in) ? lgx_in : lngamma_pos(x, false);
-  const double lgy = lngamma_pos(y, false);
-  const double lgxy = lngamma_pos(x + y, false);
+  const double lgx = (lgx_in == lgx_in) ? lgx_in : lngamma_pos(x, false, LT);
+  const double lgy = lngamma_pos(y, false, LT);
+  const double lgxy = lngamma_pos(x + y, false, LT);
   return (lgx + lgy) - lgxy;
 }
 

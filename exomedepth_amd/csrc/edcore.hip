@@ -122,6 +122,12 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
 __global__ void __launch_bounds__(256)
 k_emit_tables(const double* __restrict__ consts, int64_t S, double2* __restrict__ tab_gl, double* __restrict__ tab_lg)
 {
+  __shared__ double s_logt[ED_PM_LOGT_N * 3];   // the portable log's table, see edsf::plog_pos
+  {
+    const double T0[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+    for (int i = threadIdx.x; i < ED_PM_LOGT_N * 3; i += 256) s_logt[i] = (&T0[0][0])[i];
+  }
+  __syncthreads();
   const int64_t s = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int obs = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int st = blockIdx.z;
@@ -131,8 +137,8 @@ k_emit_tables(const double* __restrict__ consts, int64_t S, double2* __restrict_
   double lg;
   if (x > 0.0 && x < HUGE_VAL) {
     gl.x = edsf::gammastar_pos(x);
-    gl.y = edsf::plog_fast(x);
-    lg = edsf::lngamma_pos(x, false);
+    gl.y = edsf::plog_fast(x, s_logt);
+    lg = edsf::lngamma_pos(x, false, s_logt);
   } else {
     gl.x = gl.y = lg = ed_pm_nan();   // not tabulated: the task evaluates (or takes the cold path) itself
   }
@@ -166,10 +172,15 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   __shared__ double t_r[kEmitTasks];   // min/max
   __shared__ uint32_t t_i[kEmitTasks]; // where the task's tabulated terms are: index into tab_gl / tab_lg; bit 31: x is the
                                        // larger argument; 0xffffffff: not tabulated
+  __shared__ double s_logt[ED_PM_LOGT_N * 3];   // the portable log's table (3 KB), see edsf::plog_pos
   __shared__ int n_front, n_back;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   if (tid == 0) { n_front = 0; n_back = 0; }
+  {
+    const double T0[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+    for (int i = tid; i < ED_PM_LOGT_N * 3; i += kEmitBlock) s_logt[i] = (&T0[0][0])[i];
+  }
   __syncthreads();
   // The batch's exons are cut into nseg segments of whole chromosomes (job order); seg[3*i .. 3*i+2] = (first
   // workgroup, first exon, end exon) of segment i.  A workgroup owns a tile of kEmitRows exons x 64 samples (a wave
@@ -270,13 +281,13 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       double2 gl = make_double2(ed_pm_nan(), ed_pm_nan());
       if (ti != 0xffffffffu) gl = tab_gl[ti & 0x7fffffffu];
       if (ti & 0x80000000u) gl.x = -gl.x;
-      t_a[sl] = edsf::lnbeta_ratio_pre(t_a[sl], t_b[sl], t_r[sl], gl.x, gl.y);
+      t_a[sl] = edsf::lnbeta_ratio_pre(t_a[sl], t_b[sl], t_r[sl], gl.x, gl.y, s_logt);
     } else if (sl >= kEmitTasks - nb) {
       const double x = t_a[sl], y = t_b[sl];
       const uint32_t ti = t_i[sl];
       const double lgx = (ti != 0xffffffffu) ? tab_lg[ti] : ed_pm_nan();
       int flag = 0;
-      t_a[sl] = (x > 0.0 && y > 0.0) ? edsf::lnbeta_general_pre(x, y, lgx) : edsf::lnbeta_cold(x, y, &flag);
+      t_a[sl] = (x > 0.0 && y > 0.0) ? edsf::lnbeta_general_pre(x, y, lgx, s_logt) : edsf::lnbeta_cold(x, y, &flag);
       nflag += flag;
     }
   }

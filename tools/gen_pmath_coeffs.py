@@ -35,8 +35,47 @@ def max_rel_err(func, poly, a, b, npts=4001):
     return worst
 
 
+
+def log_table():
+    """The table of the table-driven log (ed_plog_core_t): 128 sub-intervals of [45/64, 90/64), boundaries on a
+    2^-8 grid below 1 and on a 2^-7 grid above (so that 1 is a boundary); row = invc = double(1/centre),
+    logc = -log(invc) split into a multiple of 2^-42 and a remainder; LN2 split the same way, so that
+    k*LN2_HI + logc_hi is exact in binary64."""
+    OFF = mp.mpf(45) / 64       # 0.703125
+    rows = []
+    for i in range(128):
+        if i < 76:
+            c = OFF + (mp.mpf(i) + mp.mpf(1) / 2) * mp.mpf(2) ** -8
+        else:
+            c = 1 + (mp.mpf(i - 76) + mp.mpf(1) / 2) * mp.mpf(2) ** -7
+        invc = mp.mpf(float(1 / c))
+        logc = -mp.log(invc)
+        hi = mp.nint(logc * mp.mpf(2) ** 42) / mp.mpf(2) ** 42
+        lo = float(logc - hi)
+        rows.append((float(invc), float(hi), lo))
+    ln2 = mp.log(2)
+    ln2hi = mp.nint(ln2 * mp.mpf(2) ** 42) / mp.mpf(2) ** 42
+    ln2lo = float(ln2 - ln2hi)
+    print("#define ED_PM_LOGT_LN2_HI %s" % float(ln2hi).hex())
+    print("#define ED_PM_LOGT_LN2_LO %s" % float(ln2lo).hex())
+    print("#define ED_PM_LOGT_N 128")
+    print("#define ED_PM_LOGT_ROWS { \\")
+    for k, (a, b, c) in enumerate(rows):
+        print("  { %s, %s, %s }%s \\" % (a.hex(), b.hex(), c.hex(), "," if k < 127 else ""))
+    print("}")
+    # check exactness claims
+    import math
+    for a, b, c in rows:
+        assert (b * 2 ** 42) == int(b * 2 ** 42)
+    assert float(ln2hi) * 2 ** 42 == int(float(ln2hi) * 2 ** 42)
+
+
 def main():
     out = []
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == 'logtable':
+        log_table()
+        return
     # ---- log: G(z) = (log((1+s)/(1-s)) - 2s) / (s*z),  z = s^2, |s| <= sqrt(2)-1 over sqrt(2)+1
     smax = (mp.sqrt(2) - 1) / (mp.sqrt(2) + 1)
     zmax = smax ** 2 * mp.mpf("1.0001")
