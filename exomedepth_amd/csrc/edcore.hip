@@ -2,12 +2,19 @@
 //
 // Kernels (names follow the reference's domain: exons, samples, chains = (sample, chromosome)):
 //   k_sample_consts   per sample: the three (a1, a2, lnbeta(a1,a2)) triples of myprob (src/CNV_estimate.cpp:44-50)
+//   k_emit_tables     per (sample, state, observed): the terms of log B that depend on the test count alone
 //   k_emit_batch      per (exon, sample) cell: three beta-binomial log-likelihoods (src/CNV_estimate.cpp:71-81)
 //   k_emit_rows       the same for per-exon phi/expected (the reference's .Call signature)
-//   k_viterbi         per chain: forward max-plus pass with back-pointers, trace-back, call count
-//                     (src/hmm.cpp:58-100, :104-126)
+//   k_viterbi         per chain: forward max-plus pass with back-pointers (src/hmm.cpp:58-90)
+//   k_tb_maps / k_tb_chain / k_tb_paths   the trace-back (src/hmm.cpp:95-100), data-parallel, + call counts
 //   k_scan_counts     exclusive scan of the per-chain call counts
 //   k_calls_fill      per chain: writes the call records (src/hmm.cpp:104-126, R/class_definition.R:371-372,:409-410)
+//   k_call_info       decoration of the calls (R/class_definition.R:379-405)
+//   k_fit_*           per-sample beta-binomial fit (aod::betabin's role, R/class_definition.R:118):
+//                     k_fit_moments/start, k_fit_hist + k_fit_hnewton (histogram form), k_fit_accum/update (per cell)
+//   edfused.inc       k_emit_viterbi: emissions + Viterbi in one kernel (optional mode)
+//   edrefset.inc      select.reference.set (R/optimize_reference_set.R:53-148)
+//   edbins.inc        phi.bins > 1 (R/class_definition.R:120-147)
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (contraction off is part of the contract:
 // the arithmetic must match the CPU checker bit for bit).
 #include <hip/hip_runtime.h>
