@@ -546,6 +546,18 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
     return {"reference.choice": choice, "summary.stats": rows, "n.bins": int(n_sel.value)}
 
 
+def get_power_betabinom(size, my_phi, my_p, my_alt_p, theory=False, frequentist=False, limit=False):
+    """reference R/tools.R:128-166 (vectorised over its arguments).  Only the default mode is on the device."""
+    if theory or frequentist or limit:
+        raise NotImplementedError("get.power.betabinom: only theory = FALSE, frequentist = FALSE, limit = FALSE is implemented")
+    size, my_phi, my_p, my_alt_p = np.broadcast_arrays(_f64(np.atleast_1d(size)), _f64(np.atleast_1d(my_phi)),
+                                                       _f64(np.atleast_1d(my_p)), _f64(np.atleast_1d(my_alt_p)))
+    size, my_phi, my_p, my_alt_p = (_f64(a) for a in (size, my_phi, my_p, my_alt_p))
+    out = np.empty(size.size, dtype=np.float64)
+    check(lib().ed_get_power_betabinom(size.size, _ptr(size), _ptr(my_phi), _ptr(my_p), _ptr(my_alt_p), _ptr(out)))
+    return out if out.size > 1 else float(out[0])
+
+
 def refset_finalize(rows, names=None):
     """Early exit + reference.choice (R/optimize_reference_set.R:130, :143-145) on a complete table of raw rows."""
     rows = np.ascontiguousarray(rows, dtype=REFSET_DTYPE).copy()

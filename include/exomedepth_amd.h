@@ -240,6 +240,11 @@ int ed_select_reference_set_part(const int32_t* d_test, const int32_t* d_refs, i
  * reference.choice (:143-145) on a complete table of raw rows.  Host code only (no device needed). */
 int ed_refset_finalize(ed_refset_row* rows, int64_t n_refs, int32_t* n_chosen);
 
+/* get.power.betabinom(size, my.phi, my.p, my.alt.p) (reference R/tools.R:128-166), default mode (theory = FALSE,
+ * frequentist = FALSE, limit = FALSE): the expected log10 Bayes factor sum_{x=0}^{size} dbetabinom(x; alt) log10 BF(x),
+ * for n parameter sets at once.  HOST arrays; synchronous. */
+int ed_get_power_betabinom(int64_t n, const double* size, const double* phi, const double* p, const double* alt_p, double* out);
+
 /* ---- utilities ---- */
 /* device memory through the library, for callers without a HIP binding (tests, R shim) */
 int ed_malloc(void** dptr, size_t bytes);

@@ -89,3 +89,19 @@ def test_prefix_shares_merge_to_the_whole(edlib):
         assert fin["reference.choice"] == whole["reference.choice"]
         if scale > 1:
             assert np.isnan(w["expected_BF"]).any()      # the early exit did trigger
+
+
+def test_get_power_betabinom_standalone(edlib):
+    """reference R/tools.R:128-166, default mode, incl. its two documented examples (my.alt.p = my.p gives 0)."""
+    from oracle import refset_oracle as ro
+    size = np.array([200, 200, 57, 1000, 3000, 0], dtype=float)
+    phi = np.array([0.1, 0.1, 0.01, 0.003, 0.02, 0.05])
+    p = np.array([0.2, 0.2, 0.1, 0.11, 0.4, 0.3])
+    alt = np.array([0.6, 0.2, 0.0526, 0.06, 0.25, 0.2])
+    got = edlib.get_power_betabinom(size, phi, p, alt)
+    exp = np.array([ro.get_power_betabinom(int(s), f, q, a) for s, f, q, a in zip(size, phi, p, alt)])
+    assert abs(got[1]) < 1e-12                                     # identical hypotheses: no evidence expected
+    assert got[0] > 1.0 and np.allclose(got, exp, rtol=1e-9, atol=1e-12), (got, exp)
+    assert isinstance(edlib.get_power_betabinom(200, 0.1, 0.2, 0.6), float)
+    with pytest.raises(NotImplementedError):
+        edlib.get_power_betabinom(200, 0.1, 0.2, 0.6, theory=True)
