@@ -99,7 +99,7 @@ while time.time() - t0 < budget:
             m = ~np.isnan(b)
             if mine != "median_depth":           # a binomial-looking prefix: the device stops at its floor 1e-6, the checker runs on to ~0
                 m &= ~(np.nan_to_num(exp["phi"], nan=1.0) < 1e-5)
-            tol_i = np.where(np.nan_to_num(exp["phi"], nan=1.0) >= 1e-4, tol, max(tol, 1e-4))   # accuracy vs phi
+            tol_i = np.maximum(tol, 1e-13 / np.nan_to_num(exp["phi"], nan=1.0) ** 2)   # ~2e-14 / phi^2
             assert np.all(np.abs(a[m] - b[m]) <= (tol_i * np.abs(b))[m]), ("refset", mine, E, R, seed, a, b)
     n[mode] += 1
 print("fuzz_more ok:", n, "%.0f s" % (time.time() - t0))
