@@ -135,7 +135,11 @@ def main():
     torch.cuda.set_device(dev)
 
     import exomedepth_amd as ed
-    from exomedepth_amd import dist as eddist
+    from exomedepth_amd import _build, dist as eddist
+    if not os.path.exists(_build.LIB) and rank == 0:   # never-built tree: compile the HIP library (there is no other path)
+        _build.build()
+    if world > 1:
+        dist.barrier()
     from exomedepth_amd import synth
 
     E, S, C = args.exons, args.samples, args.chroms

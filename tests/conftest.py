@@ -33,7 +33,9 @@ def edlib():
     except ImportError:
         pass
     import exomedepth_amd
-    from exomedepth_amd import _lib
+    from exomedepth_amd import _build, _lib
+    if not os.path.exists(_build.LIB):   # a tree that was never built (hipcc is on the GPU box too); no fallback exists
+        _build.build()
     L = _lib.lib()
     assert L.ed_device_count() > 0, "no HIP device visible: GPU tests must run on the MI355X box"
     return exomedepth_amd
