@@ -356,3 +356,33 @@ def test_call_table_grows_on_demand(edlib, oracle):
         assert len(mine) == len(exp_calls) == E
         assert np.array_equal(mine["start_exon"] + 1, exp_calls[:, 0].astype(np.int64))
         assert np.array_equal(mine["type"], exp_calls[:, 2].astype(np.int64))
+
+
+def test_argument_errors_are_reported_not_crashed(edlib):
+    """Bad arguments come back as EdError with a message (never a crash, never a silent default)."""
+    import ctypes as C
+    from exomedepth_amd._lib import lib
+    chrom_off = np.array([0, 10], dtype=np.int32)
+    start = np.arange(10, dtype=np.int32) * 100; end = start + 50
+    plan = edlib.Plan(chrom_off, start, end)
+    with pytest.raises(edlib.EdError):
+        edlib.Batch(plan, 0)
+    with pytest.raises(edlib.EdError, match="500000"):
+        edlib.Batch(plan, 600_000)
+    batch = edlib.Batch(plan, 3)
+    with pytest.raises(edlib.EdError, match="no ed_batch_run"):
+        batch.calls()
+    t = np.ones((10, 3), dtype=np.int32); r = np.full((10, 3), 9, dtype=np.int32)
+    d = edlib.DeviceArray(np.zeros(3)); e = edlib.DeviceArray(np.zeros(3))
+    with pytest.raises(edlib.EdError):
+        batch.fit(t, r, d, e, by=0)
+    with pytest.raises(edlib.EdError, match="phi_bins"):
+        batch.fit_bins(t, r, 9, edlib.DeviceArray(np.zeros((9, 3))), edlib.DeviceArray(np.zeros((10, 3))), e)
+    assert lib().ed_batch_run(batch.handle, None, None, None, None, C.c_double(1.0), None) != 0
+    with pytest.raises(edlib.EdError, match="prefix window"):
+        edlib.select_reference_set(np.ones(100, dtype=np.int32), np.ones((100, 4), dtype=np.int32), prefix_window=(3, 3))
+    with pytest.raises(ValueError):
+        edlib.viterbi_hmm(np.ones((3, 2)), np.zeros((5, 3)), np.arange(5), 1000.0)
+    with pytest.raises(edlib.EdError):                       # nstates != 3 (the reference prints and returns NULL)
+        edlib.viterbi_hmm(np.full((2, 2), 0.5), np.zeros((5, 2)), np.arange(5), 1000.0)
+    batch.close(); plan.close()
