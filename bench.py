@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
     ap.add_argument("--phi-bins", type=int, default=1, help="> 1: the depth-binned dispersion model (phi.bins, csrc/edbins.inc); "
                     "an optional mode, not the headline configuration")
+    ap.add_argument("--cov", type=int, default=0, help="> 0: the mean model with that many per-exon covariates (csrc/edcov.inc); "
+                    "an optional mode, not the headline configuration")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
@@ -157,10 +159,15 @@ def main():
     phi_fit = torch.empty(S, dtype=torch.float64, device=dev)
     p_fit = torch.empty(S, dtype=torch.float64, device=dev)
     phib_fit = torch.empty((max(args.phi_bins, 1), S), dtype=torch.float64, device=dev)
+    Xcov = (torch.rand((E, max(args.cov, 1)), dtype=torch.float64, device=dev) - 0.5) * 0.4 if args.cov > 0 else None
+    beta_fit = torch.empty((max(args.cov, 0) + 1, S), dtype=torch.float64, device=dev)
     edges_fit = torch.empty((max(args.phi_bins, 1) + 1, S), dtype=torch.float64, device=dev)
 
     def step():
-        if args.phi_bins > 1:
+        if args.cov > 0:
+            batch.fit_cov(test, ref, Xcov, beta_fit, phi_fit, stream=stream)
+            batch.run_cov(test, ref, Xcov, beta_fit, phi_fit, 1.0, stream=stream)
+        elif args.phi_bins > 1:
             batch.fit_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit, stream=stream)
             batch.run_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit, 1.0, stream=stream)
         elif args.fit:
@@ -218,7 +225,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
-                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused), "phi_bins": args.phi_bins,
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
                        "parallelism": "samples sharded, %d rank(s); call tables gathered over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": "k_emit_viterbi" if args.fused else "k_emit_batch", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

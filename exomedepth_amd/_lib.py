@@ -54,6 +54,9 @@ SYMBOLS = [
     ("ed_batch_fit_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     ("ed_batch_run_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     ("ed_batch_phi_linear", C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    ("ed_batch_fit_cov", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    ("ed_batch_run_cov", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp]),
+    ("ed_batch_expected_cov", C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     ("ed_batch_run", C.c_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp]),
     ("ed_batch_set_fused", C.c_int, [_vp, C.c_int]),
     ("ed_batch_keep_loglik", C.c_int, [_vp, C.c_int]),

@@ -291,6 +291,49 @@ class Batch:
         check(lib().ed_synchronize(None))
         return out.to_host().reshape(self.plan.n_exons, self.n_samples)
 
+    def _cov_matrix(self, X):
+        """(matrix, K) of the covariates: a host array (n_exons, K), a DeviceArray made from one, or a torch CUDA tensor."""
+        if hasattr(X, "data_ptr") or hasattr(X, "ptr"):
+            return X, int(X.shape[1])
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(self.plan.n_exons, -1)
+        return X, int(X.shape[1])
+
+    def fit_cov(self, test, ref, X, beta_out, phi_out, stream=None):
+        """Mean model with covariates (`data` + `formula ~ x1 + ...`, reference R/class_definition.R:86-118): X is the
+        (n_exons, K) covariate matrix shared by the samples; beta_out (K + 1, n_samples), phi_out (n_samples).  Synchronous."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        X, K = self._cov_matrix(X)
+        px = _device_pointer(X, np.float64, keep) if K > 0 else None
+        pb = _device_pointer(beta_out, np.float64, keep)
+        pp = _device_pointer(phi_out, np.float64, keep)
+        self._keep = keep
+        check(lib().ed_batch_fit_cov(self.handle, pt, pr, px, K, pb, pp, C.c_void_p(stream or 0)))
+
+    def run_cov(self, test, ref, X, beta, phi, mixture=1.0, stream=None):
+        """run() with expected = plogis(X beta) per exon."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        X, K = self._cov_matrix(X)
+        px = _device_pointer(X, np.float64, keep) if K > 0 else None
+        pb = _device_pointer(beta, np.float64, keep)
+        pp = _device_pointer(phi, np.float64, keep)
+        self._keep = keep
+        check(lib().ed_batch_run_cov(self.handle, pt, pr, px, K, pb, pp, float(mixture), C.c_void_p(stream or 0)))
+
+    def expected_cov(self, X, beta):
+        """(n_exons, n_samples) host array: the S4 `expected` slot, fitted(mod) = plogis(X beta)."""
+        keep = []
+        X, K = self._cov_matrix(X)
+        px = _device_pointer(X, np.float64, keep) if K > 0 else None
+        pb = _device_pointer(beta, np.float64, keep)
+        out = DeviceArray(np.zeros((self.plan.n_exons, self.n_samples)))
+        check(lib().ed_batch_expected_cov(self.handle, px, K, pb, out.ptr, None))
+        check(lib().ed_synchronize(None))
+        return out.to_host().reshape(self.plan.n_exons, self.n_samples)
+
     # ---- results ----
     def n_calls(self):
         n = C.c_int64(0)
@@ -371,7 +414,7 @@ class ExomeDepth:
     from aod::betabin, :118, :168); if omitted they are fitted on the GPU (ed_batch_fit)."""
 
     def __init__(self, test, reference, phi=None, expected=None, prop_tumor=1.0, subset_for_speed=None, phi_bins=1,
-                 verbose=False):
+                 data=None, formula="cbind(test, reference) ~ 1", verbose=False):
         test = np.asarray(test, dtype=np.float64)
         reference = np.asarray(reference, dtype=np.float64)
         if test.size != reference.size:
@@ -388,6 +431,17 @@ class ExomeDepth:
                 print("It looks like the test samples has only %d bins with more than 5 reads." % np.sum(test > 5))
             return
         n = test.size
+        self.formula = formula
+        terms = _formula_terms(formula)
+        if (phi is None or expected is None) and terms:                 # covariates: `data` columns named in the formula
+            if phi_bins != 1 or subset_for_speed is not None:
+                raise NotImplementedError("covariates together with phi.bins > 1 or subset.for.speed are not implemented")
+            if data is None:
+                raise ValueError("the formula refers to covariates but no `data` was given")
+            X = np.stack([np.asarray(data[t], dtype=np.float64) for t in terms], axis=1)
+            if X.shape[0] != n:
+                raise ValueError("`data` must have one row per exon")
+            phi, expected = fit_betabin_cov(_as_r_integer(test), _as_r_integer(reference), X)
         if (phi is None or expected is None) and phi_bins != 1:        # R/class_definition.R:120-147
             if subset_for_speed is not None:
                 raise ValueError("Subset for speed option is not compatible with variable phi. This will be fixed later on "
@@ -593,6 +647,40 @@ def fit_betabin_bins(test, reference, phi_bins):
         batch.fit_bins(t, r, phi_bins, phib, edges, exp)
         phi_lin = batch.phi_linear(r, phi_bins, phib, edges)[:, 0]
         return phi_lin, float(exp.to_host()[0])
+    finally:
+        batch.close()
+        plan.close()
+
+
+def _formula_terms(formula):
+    """Right-hand-side terms of 'cbind(test, reference) ~ x1 + x2' ('1' = intercept only -> [])."""
+    if "~" not in formula:
+        raise ValueError("formula must look like 'cbind(test, reference) ~ ...'")
+    rhs = formula.split("~", 1)[1]
+    terms = [t.strip() for t in rhs.split("+")]
+    terms = [t for t in terms if t not in ("", "1")]
+    for t in terms:
+        if not t.replace("_", "").replace(".", "").isalnum():
+            raise NotImplementedError("only main effects of numeric covariates are implemented (term %r)" % t)
+    return terms
+
+
+def fit_betabin_cov(test, reference, X):
+    """Covariate model for one sample on the GPU: returns (phi, expected per exon)."""
+    test = _i32(test)
+    reference = _i32(reference)
+    n = test.size
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(n, -1)
+    plan = Plan(np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32) + 1)
+    batch = Batch(plan, 1)
+    try:
+        beta = DeviceArray(np.zeros((X.shape[1] + 1, 1)))
+        phi = DeviceArray(np.zeros(1))
+        t = DeviceArray(test.reshape(n, 1))
+        r = DeviceArray(reference.reshape(n, 1))
+        batch.fit_cov(t, r, X, beta, phi)
+        expected = batch.expected_cov(X, beta)[:, 0]
+        return float(phi.to_host()[0]), expected
     finally:
         batch.close()
         plan.close()

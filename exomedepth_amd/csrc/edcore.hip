@@ -96,6 +96,15 @@ __device__ __forceinline__ void state_props(double e, double mixture, double ep[
   ep[2] = (e * odds_dup) / ((e * odds_dup + 1) - e);
 }
 
+// fitted(mod) = plogis(beta_0 + sum_k beta_k x_ek) for exon e, sample s (edcov.inc)
+__device__ __forceinline__ double cov_expected(const double* __restrict__ X, int K, const double* __restrict__ beta, int64_t e,
+                                               int64_t S, int64_t s)
+{
+  double eta = beta[s];
+  for (int k = 0; k < K; ++k) eta += beta[(int64_t)(k + 1) * S + s] * X[e * K + k];
+  return 1.0 / (1.0 + ed_pexp(-eta));
+}
+
 // consts layout: [9][S] = a1_del,a2_del,C_del, a1_norm,a2_norm,C_norm, a1_dup,a2_dup,C_dup ; flags[3][S]
 __global__ void k_sample_consts(const double* __restrict__ phi, const double* __restrict__ expected, double mixture,
                                 int64_t S, double* __restrict__ consts, int* __restrict__ cflags)
@@ -871,14 +880,14 @@ __device__ __forceinline__ double signif3(double x)
 __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, const double* __restrict__ loglik,
                             const double* __restrict__ consts, const int32_t* __restrict__ test,
                             const int32_t* __restrict__ ref, const double* __restrict__ expected, int64_t S,
-                            ed_call_info* __restrict__ out)
+                            ed_call_info* __restrict__ out, const double* __restrict__ X, int K, const double* __restrict__ beta)
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ncalls) return;
   const ed_call c = calls[r];
   const int64_t s = c.sample;
   const int col = (c.type == 1) ? 0 : 2;   // likelihood columns: deletion, normal, duplication
-  const double p = expected[s];
+  const double p_s = (K >= 0) ? 0.0 : expected[s];
   double bh = 0, bl = 0, eh = 0, el = 0;
   int64_t obs = 0;
   for (int64_t e = c.start_exon; e <= c.end_exon; ++e) {
@@ -896,7 +905,7 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
            consts[(1 * 3 + 2) * S + s];
     }
     dd_add(bh, bl, lc - ln);
-    dd_add(eh, el, (double)tot * p);
+    dd_add(eh, el, (double)tot * ((K >= 0) ? cov_expected(X, K, beta, e, S, s) : p_s));
     obs += t;
   }
   ed_call_info o;
@@ -1521,6 +1530,9 @@ struct ed_batch {
   const int32_t* last_test = nullptr;   // inputs of the last ed_batch_run (for ed_batch_copy_call_info)
   const int32_t* last_ref = nullptr;
   const double* last_expected = nullptr;
+  const double* last_cov_X = nullptr;   // covariate model of the last run (edcov.inc): expected is per exon
+  const double* last_cov_beta = nullptr;
+  int last_cov_K = -1;
   bool ran = false;
   bool fused = false;        // run emissions + Viterbi as ONE kernel (edfused.inc) instead of two overlapped ones
   bool keep_loglik = true;   // fused mode only: also write the [E][3][S] likelihood matrix (the S4 `likelihood` slot)
@@ -1958,19 +1970,34 @@ ED_EXPORT int ed_batch_enable_timing(ed_batch* b, int enable)
   return ED_OK;
 }
 
+// How the emissions get their per-cell (phi, expected): the default model has one pair per sample; edbins.inc
+// interpolates phi from the reference depth (phi.bins > 1); edcov.inc computes expected = plogis(X beta) per exon.
+struct EmitModel {
+  int bins = 0;                   // > 0: d_phi = phi.estimates [bins][S], edges = complete.bins [(bins + 1)][S]
+  const double* edges = nullptr;
+  bool cov = false;               // true: X [E][K] covariates, beta [K + 1][S] coefficients, d_phi [S]
+  int K = 0;
+  const double* X = nullptr;
+  const double* beta = nullptr;
+};
+
 namespace {
-// edbins.inc (phi.bins > 1): emissions with a per-exon dispersion interpolated from the per-level estimates
+// edbins.inc: emissions with per-cell shape parameters (six log-Betas per cell)
 __global__ void k_emit_bins(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int B, const double* __restrict__ edges,
-                            const double* __restrict__ phib, const double* __restrict__ expected, double mixture, int64_t E, int64_t S,
-                            double* __restrict__ loglik, unsigned long long* __restrict__ nerr);
+                            const double* __restrict__ phib, const double* __restrict__ expected, const double* __restrict__ X, int K,
+                            const double* __restrict__ beta, double mixture, int64_t E, int64_t S, double* __restrict__ loglik,
+                            unsigned long long* __restrict__ nerr);
 }
 
 // bins > 0: depth-binned dispersion (d_phi = phi.estimates [bins][S], d_edges = complete.bins [(bins + 1)][S])
 static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
-                          const double* d_expected, double mixture, void* stream_, int bins, const double* d_edges)
+                          const double* d_expected, double mixture, void* stream_, const EmitModel& em)
 {
+  const int bins = em.bins;
+  const double* d_edges = em.edges;
+  const bool plain = (em.bins == 0 && !em.cov);   // per-sample (phi, expected): k_emit_batch with hoisted constants
   if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_run: NULL argument");
-  if (bins > 0 && b->fused) return ed_fail(ED_ERR_STATE, "ed_batch_run_bins: not available in fused mode");
+  if (!plain && b->fused) return ed_fail(ED_ERR_STATE, "ed_batch_run_bins / _cov: not available in fused mode");
   HIP_TRY(hipSetDevice(b->plan->device));   // the caller's thread may have another device current (one process, many GPUs)
   hipStream_t st = (hipStream_t)stream_;
   const ed_plan* p = b->plan;
@@ -1978,9 +2005,10 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   const int32_t C = p->C;
   b->stream = st;
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
+  b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 8, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  if (bins == 0) {
+  if (plain) {
     hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
                        b->d_consts, b->d_cflags);
     if (!b->fused)
@@ -2017,14 +2045,15 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       // One launch per group, except that a group following another starts with a short separate launch: the
       // previous group's Viterbi workgroups (side stream) are dispatched into the slots freed at that launch
       // boundary instead of queueing behind this group's thousands of pending workgroups.
-      const int64_t blk0 = b->seg[3 * j0], nblk = (bins > 0) ? 0 : b->seg[3 * j1] - blk0;
+      const int64_t blk0 = b->seg[3 * j0], nblk = plain ? b->seg[3 * j1] - blk0 : 0;
       const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
-      if (bins > 0 && g == 0)   // one launch over every cell; the Viterbi groups follow it
+      if (!plain && g == 0)   // one launch over every cell; the Viterbi groups follow it
       {
         const int64_t eblk = (E + kEmitBlock / 64 - 1) / (kEmitBlock / 64);   // 4 exons x 64 samples per workgroup
         hipLaunchKernelGGL(k_emit_bins, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535),
                                              (unsigned)((eblk + 65534) / 65535)),
-                           dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S, b->d_loglik,
+                           dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, em.cov ? (const double*)nullptr : d_expected, em.X,
+                           em.cov ? em.K : -1, em.beta, mixture, E, S, b->d_loglik,
                            b->d_nerr);
       }
       if (head > 0)
@@ -2071,7 +2100,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
 ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
                            const double* d_expected, double mixture, void* stream_)
 {
-  return batch_run_impl(b, d_test, d_ref, d_phi, d_expected, mixture, stream_, 0, nullptr);
+  return batch_run_impl(b, d_test, d_ref, d_phi, d_expected, mixture, stream_, EmitModel());
 }
 
 // workspace of the column-wise beta-binomial fit (shared by ed_batch_fit and ed_select_reference_set)
@@ -2301,7 +2330,8 @@ ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int6
   DevBuf dinfo;
   HIP_TRY(dinfo.alloc((size_t)k * sizeof(ed_call_info)));
   hipLaunchKernelGGL(k_call_info, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, b->stream, b->d_calls, k,
-                     (b->keep_loglik || !b->fused) ? b->d_loglik : (double*)nullptr, b->d_consts, b->last_test, b->last_ref, b->last_expected, b->S, dinfo.as<ed_call_info>());
+                     (b->keep_loglik || !b->fused) ? b->d_loglik : (double*)nullptr, b->d_consts, b->last_test, b->last_ref, b->last_expected, b->S, dinfo.as<ed_call_info>(),
+                     b->last_cov_X, b->last_cov_K, b->last_cov_beta);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipMemcpy(host_info, dinfo.p, (size_t)k * sizeof(ed_call_info), hipMemcpyDeviceToHost));
@@ -2343,3 +2373,4 @@ ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
 
 #include "edrefset.inc"
 #include "edbins.inc"
+#include "edcov.inc"

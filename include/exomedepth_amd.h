@@ -152,6 +152,20 @@ int ed_batch_run_bins(ed_batch* batch, const int32_t* d_test, const int32_t* d_r
 int ed_batch_phi_linear(ed_batch* batch, const int32_t* d_ref, int phi_bins, const double* d_phi_bins, const double* d_edges,
                         double* d_phi_out, void* stream);
 
+/* Covariates in the mean model: `data` + `formula = cbind(test, reference) ~ x1 + ... + xK` of the reference's
+ * initialiser (R/class_definition.R:86-118, :168).  aod::betabin fits one coefficient per column of the model matrix
+ * (logit link) and one dispersion; `expected` = fitted(mod) = plogis(X beta) is per exon.
+ *   d_X     double [n_exons][n_cov]  covariates, exon-major, shared by the samples of the batch (0 <= n_cov <= 3)
+ *   d_beta  double [(n_cov + 1)][n_samples]  intercept + slopes        d_phi  double [n_samples]
+ * ed_batch_fit_cov synchronises the stream before returning.  ed_batch_run_cov is ed_batch_run with the per-exon
+ * expected evaluated on the fly (not available in fused mode); ed_batch_expected_cov writes the S4 `expected`
+ * slot, double [n_exons][n_samples]. */
+int ed_batch_fit_cov(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, const double* d_X, int n_cov, double* d_beta,
+                     double* d_phi, void* stream);
+int ed_batch_run_cov(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, const double* d_X, int n_cov,
+                     const double* d_beta, const double* d_phi, double mixture, void* stream);
+int ed_batch_expected_cov(ed_batch* batch, const double* d_X, int n_cov, const double* d_beta, double* d_expected_out, void* stream);
+
 /* Emissions + Viterbi + call segmentation for the whole batch.  All pointers are DEVICE pointers.
  * d_phi/d_expected: per-sample dispersion and expected proportion (from ed_batch_fit or given).
  * Asynchronous on `stream`; results are valid after the stream is synchronised (the accessors that

@@ -60,6 +60,8 @@ def lib():
         L.edo_fit_mle.restype = C.c_int
         L.edo_fit_mle_groups.argtypes = [_ip, _ip, _ip, C.c_long, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.edo_fit_mle_groups.restype = C.c_int
+        L.edo_fit_mle_cov.argtypes = [_ip, _ip, _dp, C.c_long, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.edo_fit_mle_cov.restype = C.c_int
         L.edo_fit_nm.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.edo_fit_nm.restype = C.c_int
         _LIB = L
@@ -173,6 +175,20 @@ def fit_mle_groups(test, ref, grp, n_groups):
     if it < 0:
         raise ValueError("edo_fit_mle_groups: nothing to fit (%d)" % it)
     return phi, p.value, ll.value, it
+
+
+def fit_mle_cov(test, ref, X):
+    """High-precision MLE of (beta_0..beta_K, phi) for  cbind(test, reference) ~ x1 + ... + xK  (a `data` frame with
+    covariates, reference R/class_definition.R:118; parity unpinned).  X: (n, K) covariates."""
+    test = _i32(test); ref = _i32(ref)
+    X = _f64(np.asarray(X, dtype=np.float64).reshape(test.size, -1))
+    K = X.shape[1]
+    beta = np.zeros(K + 1)
+    phi, ll = C.c_double(), C.c_double()
+    it = lib().edo_fit_mle_cov(test, ref, X, test.size, K, beta, C.byref(phi), C.byref(ll))
+    if it < 0:
+        raise ValueError("edo_fit_mle_cov: nothing to fit (%d)" % it)
+    return beta, phi.value, ll.value, it
 
 
 def fit_nm(test, ref):
