@@ -49,3 +49,19 @@ def test_grouped_mle_reduces_to_single_group():
     phi2, p2, ll2, _ = eo.fit_mle_groups(y, r, grp, 2)
     assert ll2 >= ll1 - 1e-9 * abs(ll1)
     assert np.all(np.abs(phi2 - phi1) / phi1 < 0.2)
+
+
+def test_covariate_mle_reduces_to_intercept_only_and_recovers_a_slope():
+    rng = np.random.default_rng(9)
+    n = 4000
+    gc = rng.uniform(-0.2, 0.2, n)
+    tot = rng.poisson(600, n)
+    p = 1 / (1 + np.exp(-(-2.0 + 1.5 * gc)))
+    phi = 0.006
+    y = rng.binomial(tot, rng.beta(p * (1 - phi) / phi, (1 - p) * (1 - phi) / phi)).astype(np.int32)
+    r = (tot - y).astype(np.int32)
+    b0, phi0, ll0, _ = eo.fit_mle_cov(y, r, np.zeros((n, 0)))
+    phi1, p1, ll1, _ = eo.fit_mle(y, r)
+    assert abs(phi0 - phi1) < 1e-12 * phi1 and abs(1 / (1 + np.exp(-b0[0])) - p1) < 1e-12
+    b, ph, ll, _ = eo.fit_mle_cov(y, r, gc[:, None])
+    assert ll > ll0 and abs(b[1] - 1.5) < 0.2 and abs(b[0] + 2.0) < 0.05 and abs(ph - phi) < 0.002
