@@ -101,3 +101,36 @@ def test_mirror_formula_with_covariates(edlib, oracle):
         edlib.ExomeDepth(t, r, formula="cbind(test, reference) ~ GC")          # no data
     with pytest.raises(NotImplementedError):
         edlib.ExomeDepth(t, r, data={"GC": X[:, 0]}, formula="cbind(test, reference) ~ GC * len")
+
+
+@pytest.mark.parametrize("E,S,seed,depth", [(953, 1, 119733737, 200.0), (1713, 3, 761797754, 200.0), (3857, 30, 856114134, 200.0)])
+def test_fit_cov_hard_starts(edlib, oracle, E, S, seed, depth):
+    """Cases the randomised sweep (tools/fuzz_more.py) broke an earlier iteration on: a strong slope on a narrow covariate
+    (the intercept-only optimum is then a SADDLE of the full model: the plain Newton direction is not an ascent direction),
+    and a first dispersion step that overshoots (coordinate-wise clipping turned the direction).  The third one sent the
+    checker's own line search to phi = 1e-23 before it was boxed like the device."""
+    K = 3
+    from exomedepth_amd import synth
+    chrom_off, start, end = synth.exon_design(E, 1, seed)
+    r2 = np.random.default_rng(seed)
+    X = np.ascontiguousarray(np.stack([r2.uniform(-0.2, 0.2, E), r2.normal(0, 1, E), r2.uniform(-1, 1, E)], axis=1))
+    lam = r2.lognormal(np.log(depth), 0.6, E)
+    test = np.zeros((E, S), dtype=np.int32); ref = np.zeros((E, S), dtype=np.int32)
+    for s in range(S):
+        beta = np.concatenate([[r2.uniform(-2.4, -1.6)], r2.uniform(-0.8, 0.8, K) * np.array([2.0, 0.15, 0.3])])
+        phi_t = r2.uniform(0.003, 0.012)
+        pe = 1 / (1 + np.exp(-(beta[0] + X @ beta[1:])))
+        tot = r2.poisson(lam * 9)
+        yy = r2.binomial(tot, r2.beta(pe * (1 - phi_t) / phi_t, (1 - pe) * (1 - phi_t) / phi_t))
+        test[:, s] = yy; ref[:, s] = tot - yy
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dbeta = edlib.DeviceArray(np.zeros((K + 1, S))); dphi = edlib.DeviceArray(np.zeros(S))
+    batch.fit_cov(test, ref, X, dbeta, dphi)
+    bt, ph = dbeta.to_host(), dphi.to_host()
+    batch.close(); plan.close()
+    for s in range(S):
+        obeta, ophi, _, _ = oracle.fit_mle_cov(test[:, s], ref[:, s], X)
+        assert 1e-4 < ophi < 0.1, (s, ophi)
+        assert np.all(np.abs(bt[:, s] - obeta) < 1e-6 * np.maximum(1.0, np.abs(obeta))), (s, bt[:, s], obeta)
+        assert abs(ph[s] - ophi) < 1e-6 * ophi, (s, ph[s], ophi)
