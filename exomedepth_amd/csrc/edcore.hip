@@ -1215,7 +1215,15 @@ static_assert((kHistKy % 2) == 0 && (kHistKr % 2) == 0, "two 16-bit bins per LDS
 // LDS bins are 16 bits wide, two per 32-bit word (the LDS atomic adds 1 or 1 << 16): 8 samples fit where 4 did,
 // which halves the L2 -> L1 line traffic the kernel is bound by (a workgroup uses 32 B of every 128-B line of a
 // count row instead of 16).  A bin cannot wrap because the bins are flushed to the 32-bit global histogram of
-// this half every kHistChunk rows.  hist: [kHistHalves][kHistK][S].
+// this half every kHistChunk rows.  hist: [kHistHalves][ceil(S / 8) * 2 quads][kHistK][4]: the four samples of a quad
+// side by side and the bins of a quad contiguous, which is how k_fit_hnewton walks it (a wave = 4 samples x 16
+// consecutive bins = 256 contiguous bytes, re-read every iteration) and lets the flush below write whole lines.
+__host__ __device__ __forceinline__ int64_t hist_padded(int64_t S) { return (S + kHistSamples - 1) / kHistSamples * kHistSamples; }
+__device__ __forceinline__ int64_t hist_at(int half, int64_t v, int64_t s, int64_t Sp)
+{
+  return ((int64_t)half * (Sp >> 2) + (s >> 2)) * (kHistK * 4) + v * 4 + (s & 3);
+}
+
 __global__ void __launch_bounds__(kHistBlock)
 k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t rs, int64_t E, int64_t S,
            uint32_t* __restrict__ hist, int32_t* __restrict__ ov_y, int32_t* __restrict__ ov_r, int32_t* __restrict__ ovn,
@@ -1234,7 +1242,7 @@ k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, in
   const int j = tid & (kHistSamples - 1);
   const int64_t s = active ? grp * kHistSamples + j : S;
   uint32_t* __restrict__ h = hsm + j * (kHistK / 2);
-  uint32_t* __restrict__ hg = hist + (int64_t)half * kHistK * S;
+  const int64_t Sp = hist_padded(S);
   // this half's rows
   const int64_t r0 = (E * half) / kHistHalves, r1 = (E * (half + 1)) / kHistHalves;
   int nov = 0;   // this thread's overflow cells: stored in row order in its own region -- no atomics, and the
@@ -1287,11 +1295,12 @@ k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, in
     __syncthreads();
     // flush: this workgroup owns its (half, samples) slice of the global histogram
     for (int i = tid; i < kHistSamples * kHistK; i += kHistBlock) {
-      const int v = i / kHistSamples, jj = i % kHistSamples;
+      const int quad = i / (kHistK * 4), rem = i % (kHistK * 4);   // consecutive i = consecutive words of the slice
+      const int v = rem >> 2, jj = quad * 4 + (rem & 3);
       const int64_t ss = grp * kHistSamples + jj;
       if (active && ss < S) {
         const uint32_t cnt = (hsm[jj * (kHistK / 2) + (v >> 1)] >> ((v & 1) * 16)) & 0xffffu;
-        uint32_t* __restrict__ o = hg + (int64_t)v * S + ss;
+        uint32_t* __restrict__ o = hist + hist_at(half, v, ss, Sp);
         *o = (chunk_no == 0 ? 0u : *o) + cnt;
       }
     }
@@ -1306,6 +1315,7 @@ k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, in
 constexpr int kHnS = 4;    // samples per workgroup
 constexpr int kHnY = 256;  // strands per sample
 static_assert(kHistGroups % kHnY == 0, "every strand owns whole overflow regions");
+static_assert(kHnS == 4 && kHistSamples % 4 == 0 && kHistHalves == 2, "hist_at's quads");
 
 __global__ void __launch_bounds__(kHnS * kHnY)
 k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_y, const int32_t* __restrict__ ov_r,
@@ -1320,6 +1330,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
   const int64_t s = (int64_t)blockIdx.x * kHnS + lane;
   const bool live = s < S;
   const int64_t sc = live ? s : S - 1;
+  const int64_t Sp = hist_padded(S);
   if (y == 0) sh_over[lane] = 0;
   __syncthreads();
   int cnt[kHistGroups / kHnY];
@@ -1371,7 +1382,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
       edfit::digamma_trigamma_nolog(th, xt, rt, qt);
       const double ixa = edfit::frcp(xa), ixb = edfit::frcp(xb), ixt = edfit::frcp(xt);
       for (int v = y; v < kHistKy; v += kHnY) {
-        const uint32_t c = hist[(int64_t)v * S + sc] + hist[((int64_t)kHistK + v) * S + sc];
+        const uint32_t c = hist[hist_at(0, v, sc, Sp)] + hist[hist_at(1, v, sc, Sp)];
         if (c) {
           double x1, r1, q1;
           edfit::digamma_trigamma_nolog(a + (double)v, x1, r1, q1);
@@ -1380,7 +1391,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
         }
       }
       for (int v = y; v < kHistKr; v += kHnY) {
-        const uint32_t c = hist[(int64_t)(kHistKy + v) * S + sc] + hist[((int64_t)kHistK + kHistKy + v) * S + sc];
+        const uint32_t c = hist[hist_at(0, kHistKy + v, sc, Sp)] + hist[hist_at(1, kHistKy + v, sc, Sp)];
         if (c) {
           double x1, r1, q1;
           edfit::digamma_trigamma_nolog(b + (double)v, x1, r1, q1);
@@ -1389,7 +1400,7 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
         }
       }
       for (int v = y; v < kHistKn; v += kHnY) {
-        const uint32_t c = hist[(int64_t)(kHistKy + kHistKr + v) * S + sc] + hist[((int64_t)kHistK + kHistKy + kHistKr + v) * S + sc];
+        const uint32_t c = hist[hist_at(0, kHistKy + kHistKr + v, sc, Sp)] + hist[hist_at(1, kHistKy + kHistKr + v, sc, Sp)];
         if (c) {
           double x1, r1, q1;
           edfit::digamma_trigamma_nolog(th + (double)v, x1, r1, q1);
@@ -2120,7 +2131,7 @@ struct FitWork {
     if (hist) return ED_OK;
     const int64_t E = E_max;   // sized for the largest fit this workspace serves
     ov_cap = std::max<int64_t>(8, (E / kHistGroups) / 8 + 1);   // per (row group, sample): ~1/8 of the group's rows
-    HIP_TRY(hipMalloc((void**)&hist, (size_t)kHistHalves * kHistK * S * 4));
+    HIP_TRY(hipMalloc((void**)&hist, (size_t)kHistHalves * kHistK * hist_padded(S) * 4));
     HIP_TRY(hipMalloc((void**)&ov_y, (size_t)ov_cap * kHistGroups * S * 4));
     HIP_TRY(hipMalloc((void**)&ov_r, (size_t)ov_cap * kHistGroups * S * 4));
     HIP_TRY(hipMalloc((void**)&ovn, (size_t)kHistGroups * S * 4));

@@ -124,3 +124,23 @@ def test_mirror_phi_bins(edlib, oracle):
     assert [c["end.p"] for c in x.CNV_calls] == list(exp_calls[:, 1].astype(int))
     with pytest.raises(ValueError):
         edlib.ExomeDepth(t, r, phi_bins=B, subset_for_speed=100)
+
+
+def test_fit_bins_few_exons_per_level(edlib, oracle):
+    """949 exons in 7 depth levels at low depth: a case of tools/fuzz_more.py on which the grouped Newton iteration
+    without step control ended 20 % off in p (it now starts from the single-dispersion optimum, shifts a non-concave
+    Hessian, scales the step as a whole and backs off after an overshoot)."""
+    from exomedepth_amd import synth
+    from oracle import bins_oracle as bo
+    E, S, B, seed = 949, 1, 7, 309133923
+    chrom_off, start, end = synth.exon_design(E, 1, seed)
+    test, ref, _, _, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=2, mean_depth=30.0)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dphib = edlib.DeviceArray(np.zeros((B, S))); dedges = edlib.DeviceArray(np.zeros((B + 1, S))); dexp = edlib.DeviceArray(np.zeros(S))
+    batch.fit_bins(test, ref, B, dphib, dedges, dexp)
+    phib, exp = dphib.to_host(), dexp.to_host()
+    batch.close(); plan.close()
+    ophi, op, _, _ = bo.fit_bins(test[:, 0], ref[:, 0], B)
+    assert np.max(np.abs(phib[:, 0] - ophi) / ophi) < 1e-6, (phib[:, 0], ophi)
+    assert abs(exp[0] - op) / op < 1e-7
