@@ -2176,7 +2176,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
-  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 4, w.partial);
+  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, E >= 65536 ? 16 : 4, w.partial);
   hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done);
   if (use_hist) {
     if (tcs != 1 || trs != rrs) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
