@@ -780,36 +780,85 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict_
 // state 0): when the state changes after a zero, `start` is set; when it changes after a non-zero
 // state a call (start, x-1, state, nexons) is pushed.  Quirks kept: `start` is NOT reset when one CNV
 // state switches directly to the other (the second call inherits the first one's start), and nexons
-// restarts only at a push.  The path is read in its packed form (16 exons per 32-bit word, 8 words in
-// flight); all-normal words are skipped; a wave leaves once its chains have written all their calls.
-__global__ void __launch_bounds__(kWave)
+// restarts only at a push.  The path is read in its packed form (16 exons per 32-bit word; unused high
+// bits of a chain's last word are zero, which reads as the dummy end state).
+// A chain is cut into kCallSeg runs of words walked by different waves (one lane per sample walking a whole
+// chromosome alone left the GPU to 384 waves: 127 us of latency).  Pass 1 counts the calls each run pushes (bit
+// operations only), an LDS prefix turns the counts into the rank of each run's first call, pass 2 writes.  The loop
+// state a run inherits: the state of the exon before it (the previous word's top bits); if that is a CNV state,
+// `run_begin` and `start` are recovered by walking back to the beginning of that run of non-zero states.
+constexpr int kCallSeg = 8;
+__global__ void __launch_bounds__(kWave * kCallSeg)
 k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chrom_off,
              const int64_t* __restrict__ word_off, int64_t S, int32_t C, const int64_t* __restrict__ offsets,
              const int32_t* __restrict__ counts, ed_call* __restrict__ calls, int64_t cap)
 {
-  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  __shared__ int seg_n[kCallSeg][kWave];
+  const int lane = threadIdx.x, sg = threadIdx.y;
+  const int64_t s = (int64_t)blockIdx.x * kWave + lane;
   const int c = blockIdx.y;
-  if (s >= S) return;
+  const bool live = s < S;
+  const int64_t sc = live ? s : S - 1;
   const int64_t lo = chrom_off[c], hi = chrom_off[c + 1];
   const int64_t m = hi - lo;
   if (m <= 0) return;
-  const int32_t todo = counts[s * C + c];
-  if (!__any(todo > 0)) return;
-  const int64_t off = offsets[s * C + c];
-  const uint32_t* __restrict__ pp = ppath + word_off[c] * S + s;
-  const int64_t nw = (m + kVitTile - 1) / kVitTile;   // unused high bits of the last word are zero
-  constexpr int kW = 16;
-  // Only the positions where the state CHANGES are visited (found with bit operations on the packed word): between
-  // two changes the summary loop of the reference does nothing but count, and `nexons` -- reset at every push,
-  // incremented on every non-zero exon -- is the length of the run that ends, x - run_begin.
+  const int32_t todo = live ? counts[sc * C + c] : 0;
+  if (!__syncthreads_or(todo > 0)) return;
+  const int64_t off = offsets[sc * C + c];
+  const uint32_t* __restrict__ pp = ppath + word_off[c] * S + sc;
+  const int64_t nw = (m + kVitTile - 1) / kVitTile;
+  const int64_t w0 = nw * sg / kCallSeg, w1 = nw * (sg + 1) / kCallSeg;
+  auto state_at = [&](int64_t x) -> int { return (int)((pp[(x / kVitTile) * S] >> (2 * (int)(x % kVitTile))) & 3u); };
+  const int prev0 = (w0 > 0 && w0 < w1) ? (int)(pp[(w0 - 1) * S] >> (2 * (kVitTile - 1))) : 0;   // exon before the run
+  constexpr int kW = 8;
+  // ---- pass 1: how many calls does this run push? ----
+  int n = 0;
+  {
+    int prev = prev0;
+    for (int64_t wb = w0; wb < w1; wb += kW) {
+      uint32_t w[kW];
+#pragma unroll
+      for (int t = 0; t < kW; ++t) w[t] = (wb + t < w1) ? pp[(wb + t) * S] : 0u;
+#pragma unroll
+      for (int t = 0; t < kW; ++t) {
+        if (wb + t < w1) {
+          const uint32_t before = (w[t] << 2) | (uint32_t)prev;
+          const uint32_t diff = w[t] ^ before;
+          const uint32_t mk = (diff | (diff >> 1)) & 0x55555555u;          // positions whose state differs from the one before
+          const uint32_t nz = (before | (before >> 1)) & 0x55555555u;      // ... and the one before is a CNV state: a push
+          n += __popc(mk & nz);
+          prev = (int)(w[t] >> (2 * (kVitTile - 1)));
+        }
+      }
+    }
+    if (w1 == nw && w0 < w1 && prev != 0) ++n;   // a full last word: the dummy end observation closes the run
+  }
+  seg_n[sg][lane] = live ? n : 0;
+  __syncthreads();
+  int k = 0;
+  for (int q = 0; q < sg; ++q) k += seg_n[q][lane];
+  const int kend = k + (live ? n : 0);
+  if (!__any(k < kend)) return;
+  // ---- pass 2: the summary loop over this run ----
+  // Only the positions where the state CHANGES are visited: between two changes the reference's loop does nothing but
+  // count, and `nexons` -- reset at every push, incremented on every non-zero exon -- is the length of the run of
+  // equal states that ends, x - run_begin.
   int64_t start = -1, run_begin = 0;
-  int prev = 0, k = 0;
+  int prev = prev0;
+  if (prev0 != 0 && k < kend) {
+    int64_t rb = w0 * kVitTile - 1;                       // an exon of the CNV run the boundary cuts
+    while (rb > 0 && state_at(rb - 1) == prev0) --rb;
+    int64_t y = rb;
+    while (y > 0 && state_at(y - 1) != 0) --y;            // a direct switch between CNV states keeps the first `start`
+    run_begin = rb;
+    start = y;
+  }
   auto change = [&](int cur, int64_t x) {   // the state changes from prev to cur at exon x
     if (prev == 0) {
       start = x;
     } else {
       const int64_t r = off + k;
-      if (r < cap) {
+      if (r < cap && k < kend) {
         ed_call rec;
         rec.sample = (int32_t)s;
         rec.chrom = c;
@@ -826,27 +875,29 @@ k_calls_fill(const uint32_t* __restrict__ ppath, const int32_t* __restrict__ chr
   };
   uint32_t nxt[kW];   // the next kW words are requested before the current ones are walked
 #pragma unroll
-  for (int t = 0; t < kW; ++t) nxt[t] = (t < nw) ? pp[(int64_t)t * S] : 0u;
-  for (int64_t wb = 0; wb < nw && __any(k < todo); wb += kW) {
+  for (int t = 0; t < kW; ++t) nxt[t] = (w0 + t < w1) ? pp[(w0 + t) * S] : 0u;
+  for (int64_t wb = w0; wb < w1 && __any(k < kend); wb += kW) {
     uint32_t w[kW];
 #pragma unroll
     for (int t = 0; t < kW; ++t) w[t] = nxt[t];
 #pragma unroll
-    for (int t = 0; t < kW; ++t) nxt[t] = (wb + kW + t < nw) ? pp[(wb + kW + t) * S] : 0u;
+    for (int t = 0; t < kW; ++t) nxt[t] = (wb + kW + t < w1) ? pp[(wb + kW + t) * S] : 0u;
 #pragma unroll
     for (int t = 0; t < kW; ++t) {
-      const uint32_t before = (w[t] << 2) | (uint32_t)prev;        // state of the exon before each position
-      const uint32_t diff = w[t] ^ before;
-      uint32_t mk = (diff | (diff >> 1)) & 0x55555555u;            // one bit per position whose state differs
-      const int64_t x0 = (wb + t) * kVitTile;
-      while (mk) {
-        const int q = __builtin_ctz(mk) >> 1;
-        mk &= mk - 1;
-        change((int)((w[t] >> (2 * q)) & 3u), x0 + q);
+      if (wb + t < w1) {
+        const uint32_t before = (w[t] << 2) | (uint32_t)prev;        // state of the exon before each position
+        const uint32_t diff = w[t] ^ before;
+        uint32_t mk = (diff | (diff >> 1)) & 0x55555555u;            // one bit per position whose state differs
+        const int64_t x0 = (wb + t) * kVitTile;
+        while (mk) {
+          const int q = __builtin_ctz(mk) >> 1;
+          mk &= mk - 1;
+          change((int)((w[t] >> (2 * q)) & 3u), x0 + q);
+        }
       }
     }
   }
-  if (prev != 0 && k < todo) change(0, m);   // the dummy last observation closes a run that reaches the end
+  if (w1 == nw && prev != 0 && k < kend) change(0, m);   // the dummy last observation closes a run that reaches the end
 }
 
 // Decoration of the call table (R/class_definition.R:379-405): per call, BF = sum over its exons of
@@ -2099,7 +2150,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, b->d_counts, (C > 0 && cells > 0) ? S * C : 0,
                      b->d_offsets, b->d_total);
   if (C > 0 && cells > 0)
-    hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave), 0, st,
+    hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave, kCallSeg), 0, st,
                        b->d_ppath, p->d_chrom_off, p->d_tile_off, S, C, b->d_offsets, b->d_counts, b->d_calls, b->calls_cap);
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));
   HIP_TRY(hipGetLastError());
@@ -2301,7 +2352,7 @@ ED_EXPORT int ed_batch_n_calls(ed_batch* b, int64_t* n_calls)
     (void)hipFree(b->d_calls);
     b->d_calls = fresh;
     b->calls_cap = cap;
-    hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((b->S + kWave - 1) / kWave), (unsigned)p->C), dim3(kWave), 0, b->stream,
+    hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((b->S + kWave - 1) / kWave), (unsigned)p->C), dim3(kWave, kCallSeg), 0, b->stream,
                        b->d_ppath, p->d_chrom_off, p->d_tile_off, b->S, p->C, b->d_offsets, b->d_counts, b->d_calls, b->calls_cap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->stream));

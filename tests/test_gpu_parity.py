@@ -358,6 +358,47 @@ def test_call_table_grows_on_demand(edlib, oracle):
         assert np.array_equal(mine["type"], exp_calls[:, 2].astype(np.int64))
 
 
+def test_calls_across_segment_boundaries(edlib, oracle):
+    """k_calls_fill cuts every chain into 8 runs of words walked by different waves; a run that starts inside a CNV must
+    recover `start`, `nexons` and the direct-switch quirk (the second call inherits the first one's start) from the
+    exons before it.  Long CNVs covering several boundaries, with direct deletion -> duplication switches at varying
+    places, a chain that is one CNV from end to end, and a short chain (fewer words than runs)."""
+    S = 6
+    sizes = [1000, 37, 640, 5]
+    chrom_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    E = int(chrom_off[-1])
+    start = np.concatenate([np.arange(n) * 300 + 1000 for n in sizes]).astype(np.int32)
+    end = start + 120
+    ref = np.full((E, S), 9000, dtype=np.int32)
+    ratio = np.ones((E, S))
+    for s in range(S):
+        a, b = 90 + 61 * s, 520 + 57 * s          # chain 0: deletion [a, b), duplication [b, b + 300): direct switch
+        ratio[a:b, s] = 0.5; ratio[b:b + 300, s] = 1.5
+        if s % 2 == 0: ratio[1000:1037, s] = 1.5  # chain 1: one duplication from end to end
+        ratio[1037 + 100 + s:1037 + 600, s] = 0.5 if s % 3 else 1.5   # chain 2: a CNV reaching the chain's last exon
+        if s == 4: ratio[1677:1682, s] = 0.5      # chain 3: 5 exons, all deleted
+    test = np.rint(1000 * ratio).astype(np.int32)
+    phi = np.full(S, 1e-3); p = np.full(S, 0.1)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    batch.run(test, ref, phi, p)
+    calls, ll, path = batch.calls(), batch.loglik(), batch.path()
+    batch.close(); plan.close()
+    n_long = 0
+    for s in range(S):
+        exp_path, exp_calls = oracle.callcnvs(ll[:, :, s], chrom_off, start, end)
+        assert np.array_equal(path[:, s].astype(np.int8), exp_path)
+        mine = calls[calls["sample"] == s]
+        assert len(mine) == len(exp_calls)
+        for f, col in (("start_exon", 0), ("end_exon", 1), ("type", 2), ("nexons", 3)):
+            assert np.array_equal(mine[f] + (1 if col < 2 else 0), exp_calls[:, col].astype(np.int64)), (s, f)
+        n_long += int(np.sum(mine["nexons"] > 250))
+        # the quirk is exercised: a duplication call that starts where the deletion before it started
+        d = mine[(mine["chrom"] == 0)]
+        assert len(d) >= 2 and d["start_exon"][0] == d["start_exon"][1] and d["type"][0] == 1 and d["type"][1] == 2
+    assert n_long >= 2 * S
+
+
 def test_argument_errors_are_reported_not_crashed(edlib):
     """Bad arguments come back as EdError with a message (never a crash, never a silent default)."""
     import ctypes as C
