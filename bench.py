@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--exons", type=int, default=200_000)
     ap.add_argument("--samples", type=int, default=1024, help="samples per GPU")
     ap.add_argument("--chroms", type=int, default=24)
+    ap.add_argument("--depth", type=float, default=100.0, help="median reads per exon and sample of the synthetic counts (SURVEY.md 8d: 100)")
     ap.add_argument("--fit", type=int, default=1, help="1 (default): the step includes the per-sample dispersion fit (configs[2]); 0: phi given (configs[1] style)")
     ap.add_argument("--fused", type=int, default=0, help="1: emissions + Viterbi as one kernel (csrc/edfused.inc)")
     ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
@@ -147,7 +148,7 @@ def main():
     E, S, C = args.exons, args.samples, args.chroms
     chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
     torch.manual_seed(20250620 + 3 + rank)
-    test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=20250620 + 3 + 1000 * rank)
+    test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=20250620 + 3 + 1000 * rank, mean_depth=args.depth)
     torch.cuda.synchronize()
 
     plan = ed.Plan(chrom_off, start, end, 1e-4, 50000.0, device=local_rank)

@@ -1360,6 +1360,53 @@ k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, in
   if (s < S) ovn[(int64_t)region * S + s] = nov;
 }
 
+// One block of consecutive bins of a count histogram in the Newton sums of k_fit_hnewton.  Consecutive bins are
+// consecutive integers, so only the block's first bin is evaluated in full (difference form: psi(x0 + v) - psi(x0) =
+// ln((x0 + v)/x0) + (rest - rest0)); from there
+//     psi(x + 1) = psi(x) + 1/x,     psi'(x + 1) = psi'(x) - 1/x^2
+// carry the two differences along: one reciprocal per bin instead of a digamma, a trigamma and a logarithm.  The psi
+// recurrence is summed error-free (TwoSum into a low word), so a bin's value is as accurate as the block's first one;
+// for psi' (curvature only) the plain sum's few roundings are immaterial.
+// Counts: global histogram halves g0, g1 (one bin every 4 words; either may be null) plus packed 16-bit LDS bins
+// (l, first bin li; null = none).  x = shape parameter + value of the block's first bin; (ix0, r0, q0) describe the
+// reference point x0 as digamma_trigamma_nolog(x0) returns it (1/xs, rest, psi').  Returns (sum c dpsi, sum c dpsi').
+__device__ __noinline__ double2 hn_block(double x, int nb, const uint32_t* __restrict__ g0, const uint32_t* __restrict__ g1,
+                                         const uint32_t* l, int li, double ix0, double r0, double q0)
+{
+  double x1, r1, q1;
+  edfit::digamma_trigamma_nolog(x, x1, r1, q1);
+  double dh = edfit::flog(x1 * ix0) + (r1 - r0), dl = 0.0;   // psi(x) - psi(x0), high and low word
+  double dq = q1 - q0;                                       // psi'(x) - psi'(x0)
+  double g = 0.0, h = 0.0;
+  for (int k = 0; k < nb; ++k) {
+    uint32_t c = 0;
+    if (g0) c += g0[4 * k];
+    if (g1) c += g1[4 * k];
+    if (l) c += (l[(li + k) >> 1] >> (((li + k) & 1) * 16)) & 0xffffu;
+    const double cd = (double)c;
+    g = __builtin_fma(cd, dh + dl, g);
+    h = __builtin_fma(cd, dq, h);
+    const double r = edfit::frcp(x + (double)k);
+    const double t = dh + r;                                 // TwoSum(dh, r)
+    const double bb = t - dh;
+    dl += (dh - (t - bb)) + (r - bb);
+    dh = t;
+    dq = __builtin_fma(-r, r, dq);
+  }
+  return make_double2(g, h);
+}
+
+// Second level of the histograms, in LDS of k_fit_hnewton: the cells k_fit_hist could not place (a count beyond its
+// bins; 3 % of the cells at ~100 reads per exon and sample, 15 % at ~200) were evaluated one by one in every
+// iteration -- as costly as all the bins together at 3 %, the whole fit at 15 % (9.4 ms).  A cell lands there
+// because n >= kHistKn (then r = n - y > kHistKn - kHistKy when y is in range), so two more ranges of kOv2 unit bins,
+// r in [kOv2R0, kOv2R0 + kOv2) and n in [kHistKn, kHistKn + kOv2), built once per launch from the overflow lists,
+// take most of them; what is still outside stays a list (compacted in place) and is evaluated per cell.
+constexpr int kOv2 = 5120;
+constexpr int kOv2R0 = kHistKr - kHistKy;
+constexpr int kOv2Words = (kHistKy + 2 * kOv2) / 2;   // 16-bit bins, two per word: y | r | n
+static_assert(kHistKy % 2 == 0 && kOv2 % 2 == 0, "packed pairs");
+
 // All Newton iterations of 4 samples in one launch: 256 strands per sample share the bins and the overflow
 // regions (strand y: bins y, y + 256, ...; row group y), a fixed-order LDS tree adds them up,
 // strand 0 takes the step.
@@ -1367,9 +1414,10 @@ constexpr int kHnS = 4;    // samples per workgroup
 constexpr int kHnY = 256;  // strands per sample
 static_assert(kHistGroups % kHnY == 0, "every strand owns whole overflow regions");
 static_assert(kHnS == 4 && kHistSamples % 4 == 0 && kHistHalves == 2, "hist_at's quads");
+static_assert(kHistKy % kHnY == 0 && kHistKr % kHnY == 0 && kHistKn % kHnY == 0 && kOv2 % kHnY == 0, "whole blocks per strand");
 
 __global__ void __launch_bounds__(kHnS * kHnY)
-k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_y, const int32_t* __restrict__ ov_r,
+k_fit_hnewton(const uint32_t* __restrict__ hist, int32_t* __restrict__ ov_y, int32_t* __restrict__ ov_r,
               const int32_t* __restrict__ ovn, int64_t cap, int64_t S, double* __restrict__ eta, double* __restrict__ lam,
               int* __restrict__ done, int max_iter, double tol, const int32_t* __restrict__ test,
               const int32_t* __restrict__ ref, int64_t rs, int64_t E)
@@ -1377,7 +1425,12 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
   __shared__ double lds[kFitQ][kHnY][kHnS];
   __shared__ double sh_eta[kHnS], sh_lam[kHnS];
   __shared__ int sh_done[kHnS], sh_over[kHnS];
+  __shared__ uint32_t ov2[kHnS][kOv2Words];
+  __shared__ int res_pre[kHnS][kHnY + 1];   // exclusive prefix over the strands' lists of the cells still evaluated one by one
+  constexpr int kResLds = 512;              // ... the first kResLds of them per sample are kept here (y, r)
+  __shared__ int res_y[kHnS][kResLds], res_r[kHnS][kResLds];
   const int lane = threadIdx.x, y = threadIdx.y;
+  for (int i = y * kHnS + lane; i < kHnS * kOv2Words; i += kHnS * kHnY) (&ov2[0][0])[i] = 0u;
   const int64_t s = (int64_t)blockIdx.x * kHnS + lane;
   const bool live = s < S;
   const int64_t sc = live ? s : S - 1;
@@ -1398,6 +1451,46 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
     sh_eta[lane] = eta[sc];
     sh_lam[lane] = lam[sc];
     sh_done[lane] = live ? done[sc] : 1;
+  }
+  __syncthreads();
+  // second-level bins from the overflow lists (16-bit: a list holds at most cap <= 255 cells and there are 256 lists)
+  if (fits && !sh_done[lane]) {
+#pragma unroll
+    for (int k = 0; k < kHistGroups / kHnY; ++k) {
+      const int64_t base = (int64_t)(y + k * kHnY) * cap;
+      int nres = 0;
+      for (int i = 0; i < cnt[k]; ++i) {
+        const int yy = ov_y[(base + i) * S + sc], rr = ov_r[(base + i) * S + sc];
+        const unsigned ri = (unsigned)(rr - kOv2R0), ni = (unsigned)(yy + rr - kHistKn);
+        if ((unsigned)yy < (unsigned)kHistKy && ri < (unsigned)kOv2 && ni < (unsigned)kOv2) {
+          const int by = yy, br = kHistKy + (int)ri, bn = kHistKy + kOv2 + (int)ni;
+          atomicAdd(&ov2[lane][by >> 1], 1u << ((by & 1) * 16));
+          atomicAdd(&ov2[lane][br >> 1], 1u << ((br & 1) * 16));
+          atomicAdd(&ov2[lane][bn >> 1], 1u << ((bn & 1) * 16));
+        } else {
+          if (nres != i) { ov_y[(base + nres) * S + sc] = yy; ov_r[(base + nres) * S + sc] = rr; }   // this strand's list only
+          ++nres;
+        }
+      }
+      cnt[k] = nres;
+    }
+  }
+  static_assert(kHistGroups == kHnY, "one overflow list per strand (res_pre)");
+  res_pre[lane][y + 1] = (fits && !sh_done[lane]) ? cnt[0] : 0;
+  __syncthreads();
+  if (y == 0) {
+    int run = 0;
+    res_pre[lane][0] = 0;
+    for (int g = 1; g <= kHnY; ++g) { run += res_pre[lane][g]; res_pre[lane][g] = run; }
+  }
+  __syncthreads();
+  if (fits && !sh_done[lane]) {
+    const int64_t base = (int64_t)y * cap;
+    const int q0 = res_pre[lane][y];
+    for (int i = 0; i < cnt[0] && q0 + i < kResLds; ++i) {
+      res_y[lane][q0 + i] = ov_y[(base + i) * S + sc];
+      res_r[lane][q0 + i] = ov_r[(base + i) * S + sc];
+    }
   }
   __syncthreads();
   for (int it = 0; it < max_iter; ++it) {
@@ -1432,46 +1525,55 @@ k_fit_hnewton(const uint32_t* __restrict__ hist, const int32_t* __restrict__ ov_
       edfit::digamma_trigamma_nolog(b, xb, rb, qb);
       edfit::digamma_trigamma_nolog(th, xt, rt, qt);
       const double ixa = edfit::frcp(xa), ixb = edfit::frcp(xb), ixt = edfit::frcp(xt);
-      for (int v = y; v < kHistKy; v += kHnY) {
-        const uint32_t c = hist[hist_at(0, v, sc, Sp)] + hist[hist_at(1, v, sc, Sp)];
-        if (c) {
-          double x1, r1, q1;
-          edfit::digamma_trigamma_nolog(a + (double)v, x1, r1, q1);
-          acc[0] += (double)c * (edfit::flog(x1 * ixa) + (r1 - ra));
-          acc[2] += (double)c * (q1 - qa);
-        }
+      // a strand owns a block of consecutive bins of each histogram (first level 4 / 16 / 16, second level 20 / 20)
+      {
+        constexpr int nb = kHistKy / kHnY;
+        const double2 t = hn_block(a + (double)(y * nb), nb, hist + hist_at(0, y * nb, sc, Sp), hist + hist_at(1, y * nb, sc, Sp),
+                                   ov2[lane], y * nb, ixa, ra, qa);
+        acc[0] += t.x; acc[2] += t.y;
       }
-      for (int v = y; v < kHistKr; v += kHnY) {
-        const uint32_t c = hist[hist_at(0, kHistKy + v, sc, Sp)] + hist[hist_at(1, kHistKy + v, sc, Sp)];
-        if (c) {
-          double x1, r1, q1;
-          edfit::digamma_trigamma_nolog(b + (double)v, x1, r1, q1);
-          acc[1] += (double)c * (edfit::flog(x1 * ixb) + (r1 - rb));
-          acc[4] += (double)c * (q1 - qb);
-        }
+      {
+        constexpr int nb = kHistKr / kHnY;
+        const double2 t = hn_block(b + (double)(y * nb), nb, hist + hist_at(0, kHistKy + y * nb, sc, Sp),
+                                   hist + hist_at(1, kHistKy + y * nb, sc, Sp), nullptr, 0, ixb, rb, qb);
+        acc[1] += t.x; acc[4] += t.y;
       }
-      for (int v = y; v < kHistKn; v += kHnY) {
-        const uint32_t c = hist[hist_at(0, kHistKy + kHistKr + v, sc, Sp)] + hist[hist_at(1, kHistKy + kHistKr + v, sc, Sp)];
-        if (c) {
-          double x1, r1, q1;
-          edfit::digamma_trigamma_nolog(th + (double)v, x1, r1, q1);
-          const double cd = (double)c;
-          const double dps = cd * (edfit::flog(x1 * ixt) + (r1 - rt)), dq = cd * (q1 - qt);
-          acc[0] -= dps; acc[1] -= dps;
-          acc[2] -= dq; acc[3] -= dq; acc[4] -= dq;
-        }
+      {
+        constexpr int nb = kHistKn / kHnY;
+        const double2 t = hn_block(th + (double)(y * nb), nb, hist + hist_at(0, kHistKy + kHistKr + y * nb, sc, Sp),
+                                   hist + hist_at(1, kHistKy + kHistKr + y * nb, sc, Sp), nullptr, 0, ixt, rt, qt);
+        acc[0] -= t.x; acc[1] -= t.x;
+        acc[2] -= t.y; acc[3] -= t.y; acc[4] -= t.y;
+      }
+      {
+        constexpr int nb = kOv2 / kHnY;
+        const double2 tr = hn_block(b + (double)(kOv2R0 + y * nb), nb, nullptr, nullptr, ov2[lane], kHistKy + y * nb, ixb, rb, qb);
+        acc[1] += tr.x; acc[4] += tr.y;
+        const double2 t = hn_block(th + (double)(kHistKn + y * nb), nb, nullptr, nullptr, ov2[lane], kHistKy + kOv2 + y * nb, ixt, rt, qt);
+        acc[0] -= t.x; acc[1] -= t.x;
+        acc[2] -= t.y; acc[3] -= t.y; acc[4] -= t.y;
       }
       // cells beyond the bins: evaluated whole, minus the same constant terms
       const double ca = edfit::flog(xa * ixt) + (ra - rt), cb = edfit::flog(xb * ixt) + (rb - rt);
-#pragma unroll
-      for (int k = 0; k < kHistGroups / kHnY; ++k) {
-        const int64_t base = (int64_t)(y + k * kHnY) * cap;
-        for (int i = 0; i < cnt[k]; ++i) {
-          const int yy = ov_y[(base + i) * S + sc], rr = ov_r[(base + i) * S + sc];
-          edfit::Acc c = {0, 0, 0, 0, 0};
-          edfit::accumulate_cell(c, a, b, th, yy, yy + rr);
-          acc[0] += c.ga - ca; acc[1] += c.gb - cb; acc[2] += c.haa - (qa - qt); acc[3] += c.hab + qt; acc[4] += c.hbb - (qb - qt);
+      // the lists differ in length (a few cells each, Poisson): walked list by list, a wave would take as long as its
+      // longest list; instead the strands share the concatenation of the sample's lists round-robin
+      const int n_res = res_pre[lane][kHnY];
+      for (int q = y; q < n_res; q += kHnY) {
+        int yy, rr;
+        if (q < kResLds) {
+          yy = res_y[lane][q]; rr = res_r[lane][q];
+        } else {   // deep data: the rest from the lists themselves (which list? binary search in the prefix)
+          int lo_g = 0, hi_g = kHnY;
+          while (hi_g - lo_g > 1) {
+            const int mid = (lo_g + hi_g) >> 1;
+            if (res_pre[lane][mid] <= q) lo_g = mid; else hi_g = mid;
+          }
+          const int64_t slot = (int64_t)lo_g * cap + (q - res_pre[lane][lo_g]);
+          yy = ov_y[slot * S + sc]; rr = ov_r[slot * S + sc];
         }
+        edfit::Acc c = {0, 0, 0, 0, 0};
+        edfit::accumulate_cell(c, a, b, th, yy, yy + rr);
+        acc[0] += c.ga - ca; acc[1] += c.gb - cb; acc[2] += c.haa - (qa - qt); acc[3] += c.hab + qt; acc[4] += c.hbb - (qb - qt);
       }
     }
     // acc[5] (the cell count that scales the constant terms in fit_newton_step) stays 0: they are already in
@@ -2181,7 +2283,9 @@ struct FitWork {
   {
     if (hist) return ED_OK;
     const int64_t E = E_max;   // sized for the largest fit this workspace serves
-    ov_cap = std::max<int64_t>(8, (E / kHistGroups) / 8 + 1);   // per (row group, sample): ~1/8 of the group's rows
+    // per (row group, sample): ~1/3 of the group's rows, at most 255 (the 16-bit second-level bins of k_fit_hnewton count
+    // the cells of the 256 lists of a sample: 256 x 255 < 65536)
+    ov_cap = std::min<int64_t>(255, std::max<int64_t>(8, (E / kHistGroups) / 3 + 1));
     HIP_TRY(hipMalloc((void**)&hist, (size_t)kHistHalves * kHistK * hist_padded(S) * 4));
     HIP_TRY(hipMalloc((void**)&ov_y, (size_t)ov_cap * kHistGroups * S * 4));
     HIP_TRY(hipMalloc((void**)&ov_r, (size_t)ov_cap * kHistGroups * S * 4));
