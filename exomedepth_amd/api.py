@@ -224,8 +224,9 @@ class Batch:
         check(lib().ed_batch_keep_loglik(self.handle, 1 if keep else 0))
 
     def set_fit_histograms(self, on=True):
-        """fit(): iterate on per-sample count histograms (default) or per cell on every pass."""
-        check(lib().ed_batch_set_fit_histograms(self.handle, 1 if on else 0))
+        """fit(): iterate on per-sample count histograms (default; True / 1: geometry picked from the data's depth,
+        8 / 4 / 2: that geometry) or per cell on every pass (False / 0)."""
+        check(lib().ed_batch_set_fit_histograms(self.handle, int(on)))
 
     @property
     def n_emit_launches(self):

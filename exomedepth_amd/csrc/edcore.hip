@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 //   sum_e (y - n p)^2 / (n p q) ~ cnt + phi * sum_e (n - 1)
 __global__ void __launch_bounds__(kWave * kRedY)
 k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
-            double* __restrict__ lam, int* __restrict__ done)
+            double* __restrict__ lam, int* __restrict__ done, int* __restrict__ depth_max)
 {
   __shared__ double lds[kFitQ][kRedY][kWave];
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
@@ -1089,6 +1089,8 @@ k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, doubl
   eta[s] = ed_plog(p / q);
   lam[s] = ed_plog((1.0 - phi) / phi);
   done[s] = (cnt < 2.0) ? 1 : 0;   // nothing to fit
+  // the batch's depth (largest per-sample mean total): picks the histogram geometry, see fit_hist_geometry
+  if (cnt > 0) atomicMax(depth_max, (int)fmin(sn / cnt, 2.0e9));
 }
 
 __global__ void __launch_bounds__(kWave * kFitSub)
@@ -1251,358 +1253,27 @@ k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, doub
 // with a count beyond the histogram range go to a per-sample overflow list and are evaluated one by one; a
 // sample whose list overflows, or that has not converged, is finished by the per-cell kernels above.
 // (Sums are grouped by value instead of by exon: the result differs from the per-cell path by rounding only.)
-constexpr int kHistKy = 1024;                            // bins of the test count
-constexpr int kHistKr = 4096;                            // bins of the reference count
-constexpr int kHistKn = 4096;                            // bins of the total
-constexpr int kHistK = kHistKy + kHistKr + kHistKn;
-constexpr int kHistSamples = 8;                          // samples per workgroup: 8 x 9216 x 2 B = 147 456 B of LDS
-constexpr int kHistBlock = 1024;
-constexpr int kHistHalves = 2;                           // workgroups per sample group: each takes half of the rows
-constexpr int kHistRows = kHistBlock / kHistSamples;     // rows per sweep of a workgroup
-constexpr int kHistGroups = kHistHalves * kHistRows;     // (half, thread row) pairs = overflow regions per sample
-constexpr int kHistChunk = 65535;                        // rows between flushes: a 16-bit bin cannot wrap
-static_assert((kHistKy % 2) == 0 && (kHistKr % 2) == 0, "two 16-bit bins per LDS word");
+// Which geometry serves a batch: depth = the largest per-sample mean total count n (k_fit_start).  The unit bins plus
+// the second level of k_fit_hnewton reach n = 9216 / 13312 / 21504; they should cover ~5 x the mean (the synthetic
+// design's log-normal exon depths put 99.5 % of the cells below that).  Never a matter of correctness: cells beyond
+// the bins are evaluated one by one.
+__global__ void k_set_int(int* p, int v) { *p = v; }
+__host__ __device__ __forceinline__ int fit_hist_geometry(int depth) { return depth <= 1843 ? 8 : (depth <= 2662 ? 4 : 2); }
 
-// LDS bins are 16 bits wide, two per 32-bit word (the LDS atomic adds 1 or 1 << 16): 8 samples fit where 4 did,
-// which halves the L2 -> L1 line traffic the kernel is bound by (a workgroup uses 32 B of every 128-B line of a
-// count row instead of 16).  A bin cannot wrap because the bins are flushed to the 32-bit global histogram of
-// this half every kHistChunk rows.  hist: [kHistHalves][ceil(S / 8) * 2 quads][kHistK][4]: the four samples of a quad
-// side by side and the bins of a quad contiguous, which is how k_fit_hnewton walks it (a wave = 4 samples x 16
-// consecutive bins = 256 contiguous bytes, re-read every iteration) and lets the flush below write whole lines.
-__host__ __device__ __forceinline__ int64_t hist_padded(int64_t S) { return (S + kHistSamples - 1) / kHistSamples * kHistSamples; }
-__device__ __forceinline__ int64_t hist_at(int half, int64_t v, int64_t s, int64_t Sp)
-{
-  return ((int64_t)half * (Sp >> 2) + (s >> 2)) * (kHistK * 4) + v * 4 + (s & 3);
+namespace hg8 {
+#define ED_HG_KS 8
+#include "edfit_hist.inc"
+#undef ED_HG_KS
 }
-
-__global__ void __launch_bounds__(kHistBlock)
-k_fit_hist(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t rs, int64_t E, int64_t S,
-           uint32_t* __restrict__ hist, int32_t* __restrict__ ov_y, int32_t* __restrict__ ov_r, int32_t* __restrict__ ovn,
-           int64_t cap)   // cap: overflow cells per (overflow region, sample)
-{
-  __shared__ uint32_t hsm[kHistSamples * (kHistK / 2)];
-  const int tid = threadIdx.x;
-  // Workgroups are dealt to the 8 XCDs round-robin, and neighbouring sample groups share every 128-byte line of a
-  // count row: neighbours must sit on the SAME XCD (one L2) or each line is fetched several times.  So XCD x
-  // (= blockIdx % 8) owns a contiguous range of the (half, sample group) pairs, half-major.
-  const int64_t ng = (S + kHistSamples - 1) / kHistSamples, nwg = ng * kHistHalves, per = (nwg + 7) / 8;
-  const int64_t lin = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const bool active = (int64_t)(blockIdx.x >> 3) < per && lin < nwg;
-  const int half = active ? (int)(lin / ng) : 0;
-  const int64_t grp = active ? lin % ng : 0;
-  const int j = tid & (kHistSamples - 1);
-  const int64_t s = active ? grp * kHistSamples + j : S;
-  uint32_t* __restrict__ h = hsm + j * (kHistK / 2);
-  const int64_t Sp = hist_padded(S);
-  // this half's rows
-  const int64_t r0 = (E * half) / kHistHalves, r1 = (E * (half + 1)) / kHistHalves;
-  int nov = 0;   // this thread's overflow cells: stored in row order in its own region -- no atomics, and the
-                 // order in which k_fit_hnewton adds them up is the same on every run
-  const int region = half * kHistRows + tid / kHistSamples;
-  const int64_t ovbase = (int64_t)region * cap;
-  auto bump = [&](int v) { atomicAdd(&h[v >> 1], 1u << ((v & 1) * 16)); };
-  int chunk_no = 0;
-  for (int64_t c0 = r0; c0 < r1 || chunk_no == 0; c0 += kHistChunk, ++chunk_no) {
-    const int64_t c1 = (c0 + kHistChunk < r1) ? c0 + kHistChunk : r1;
-    for (int i = tid; i < kHistSamples * (kHistK / 2); i += kHistBlock) hsm[i] = 0;
-    __syncthreads();
-    if (s < S) {
-      constexpr int kPre = 4;                              // rows in flight per thread
-      int yb[kPre], rb[kPre];
-      const int64_t e0 = c0 + tid / kHistSamples;
-#pragma unroll
-      for (int k = 0; k < kPre; ++k) {
-        const int64_t e = e0 + (int64_t)k * kHistRows;
-        yb[k] = (e < c1) ? test[e * rs + s] : 0;
-        rb[k] = (e < c1) ? ref[e * rs + s] : 0;
-      }
-      for (int64_t e = e0; e < c1; e += (int64_t)kPre * kHistRows) {
-        int yc[kPre], rc[kPre];
-#pragma unroll
-        for (int k = 0; k < kPre; ++k) { yc[k] = yb[k]; rc[k] = rb[k]; }
-#pragma unroll
-        for (int k = 0; k < kPre; ++k) {
-          const int64_t en = e + (int64_t)(kPre + k) * kHistRows;
-          yb[k] = (en < c1) ? test[en * rs + s] : 0;
-          rb[k] = (en < c1) ? ref[en * rs + s] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < kPre; ++k) {
-          if (e + (int64_t)k * kHistRows >= c1) break;
-          const int y = yc[k], r = rc[k];
-          const int n = y + r;
-          if (n <= 0) continue;   // carries no information (and is not counted), as in accumulate_cell
-          if ((unsigned)y < (unsigned)kHistKy && (unsigned)r < (unsigned)kHistKr && (unsigned)n < (unsigned)kHistKn) {
-            bump(y);
-            bump(kHistKy + r);
-            bump(kHistKy + kHistKr + n);
-          } else {
-            if (nov < cap) { ov_y[(ovbase + nov) * S + s] = y; ov_r[(ovbase + nov) * S + s] = r; }
-            ++nov;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // flush: this workgroup owns its (half, samples) slice of the global histogram
-    for (int i = tid; i < kHistSamples * kHistK; i += kHistBlock) {
-      const int quad = i / (kHistK * 4), rem = i % (kHistK * 4);   // consecutive i = consecutive words of the slice
-      const int v = rem >> 2, jj = quad * 4 + (rem & 3);
-      const int64_t ss = grp * kHistSamples + jj;
-      if (active && ss < S) {
-        const uint32_t cnt = (hsm[jj * (kHistK / 2) + (v >> 1)] >> ((v & 1) * 16)) & 0xffffu;
-        uint32_t* __restrict__ o = hist + hist_at(half, v, ss, Sp);
-        *o = (chunk_no == 0 ? 0u : *o) + cnt;
-      }
-    }
-    __syncthreads();
-  }
-  if (s < S) ovn[(int64_t)region * S + s] = nov;
+namespace hg4 {
+#define ED_HG_KS 4
+#include "edfit_hist.inc"
+#undef ED_HG_KS
 }
-
-// One block of consecutive bins of a count histogram in the Newton sums of k_fit_hnewton.  Consecutive bins are
-// consecutive integers, so only the block's first bin is evaluated in full (difference form: psi(x0 + v) - psi(x0) =
-// ln((x0 + v)/x0) + (rest - rest0)); from there
-//     psi(x + 1) = psi(x) + 1/x,     psi'(x + 1) = psi'(x) - 1/x^2
-// carry the two differences along: one reciprocal per bin instead of a digamma, a trigamma and a logarithm.  The psi
-// recurrence is summed error-free (TwoSum into a low word), so a bin's value is as accurate as the block's first one;
-// for psi' (curvature only) the plain sum's few roundings are immaterial.
-// Counts: global histogram halves g0, g1 (one bin every 4 words; either may be null) plus packed 16-bit LDS bins
-// (l, first bin li; null = none).  x = shape parameter + value of the block's first bin; (ix0, r0, q0) describe the
-// reference point x0 as digamma_trigamma_nolog(x0) returns it (1/xs, rest, psi').  Returns (sum c dpsi, sum c dpsi').
-__device__ __noinline__ double2 hn_block(double x, int nb, const uint32_t* __restrict__ g0, const uint32_t* __restrict__ g1,
-                                         const uint32_t* l, int li, double ix0, double r0, double q0)
-{
-  double x1, r1, q1;
-  edfit::digamma_trigamma_nolog(x, x1, r1, q1);
-  double dh = edfit::flog(x1 * ix0) + (r1 - r0), dl = 0.0;   // psi(x) - psi(x0), high and low word
-  double dq = q1 - q0;                                       // psi'(x) - psi'(x0)
-  double g = 0.0, h = 0.0;
-  for (int k = 0; k < nb; ++k) {
-    uint32_t c = 0;
-    if (g0) c += g0[4 * k];
-    if (g1) c += g1[4 * k];
-    if (l) c += (l[(li + k) >> 1] >> (((li + k) & 1) * 16)) & 0xffffu;
-    const double cd = (double)c;
-    g = __builtin_fma(cd, dh + dl, g);
-    h = __builtin_fma(cd, dq, h);
-    const double r = edfit::frcp(x + (double)k);
-    const double t = dh + r;                                 // TwoSum(dh, r)
-    const double bb = t - dh;
-    dl += (dh - (t - bb)) + (r - bb);
-    dh = t;
-    dq = __builtin_fma(-r, r, dq);
-  }
-  return make_double2(g, h);
-}
-
-// Second level of the histograms, in LDS of k_fit_hnewton: the cells k_fit_hist could not place (a count beyond its
-// bins; 3 % of the cells at ~100 reads per exon and sample, 15 % at ~200) were evaluated one by one in every
-// iteration -- as costly as all the bins together at 3 %, the whole fit at 15 % (9.4 ms).  A cell lands there
-// because n >= kHistKn (then r = n - y > kHistKn - kHistKy when y is in range), so two more ranges of kOv2 unit bins,
-// r in [kOv2R0, kOv2R0 + kOv2) and n in [kHistKn, kHistKn + kOv2), built once per launch from the overflow lists,
-// take most of them; what is still outside stays a list (compacted in place) and is evaluated per cell.
-constexpr int kOv2 = 5120;
-constexpr int kOv2R0 = kHistKr - kHistKy;
-constexpr int kOv2Words = (kHistKy + 2 * kOv2) / 2;   // 16-bit bins, two per word: y | r | n
-static_assert(kHistKy % 2 == 0 && kOv2 % 2 == 0, "packed pairs");
-
-// All Newton iterations of 4 samples in one launch: 256 strands per sample share the bins and the overflow
-// regions (strand y: bins y, y + 256, ...; row group y), a fixed-order LDS tree adds them up,
-// strand 0 takes the step.
-constexpr int kHnS = 4;    // samples per workgroup
-constexpr int kHnY = 256;  // strands per sample
-static_assert(kHistGroups % kHnY == 0, "every strand owns whole overflow regions");
-static_assert(kHnS == 4 && kHistSamples % 4 == 0 && kHistHalves == 2, "hist_at's quads");
-static_assert(kHistKy % kHnY == 0 && kHistKr % kHnY == 0 && kHistKn % kHnY == 0 && kOv2 % kHnY == 0, "whole blocks per strand");
-
-__global__ void __launch_bounds__(kHnS * kHnY)
-k_fit_hnewton(const uint32_t* __restrict__ hist, int32_t* __restrict__ ov_y, int32_t* __restrict__ ov_r,
-              const int32_t* __restrict__ ovn, int64_t cap, int64_t S, double* __restrict__ eta, double* __restrict__ lam,
-              int* __restrict__ done, int max_iter, double tol, const int32_t* __restrict__ test,
-              const int32_t* __restrict__ ref, int64_t rs, int64_t E)
-{
-  __shared__ double lds[kFitQ][kHnY][kHnS];
-  __shared__ double sh_eta[kHnS], sh_lam[kHnS];
-  __shared__ int sh_done[kHnS], sh_over[kHnS];
-  __shared__ uint32_t ov2[kHnS][kOv2Words];
-  __shared__ int res_pre[kHnS][kHnY + 1];   // exclusive prefix over the strands' lists of the cells still evaluated one by one
-  constexpr int kResLds = 512;              // ... the first kResLds of them per sample are kept here (y, r)
-  __shared__ int res_y[kHnS][kResLds], res_r[kHnS][kResLds];
-  const int lane = threadIdx.x, y = threadIdx.y;
-  for (int i = y * kHnS + lane; i < kHnS * kOv2Words; i += kHnS * kHnY) (&ov2[0][0])[i] = 0u;
-  const int64_t s = (int64_t)blockIdx.x * kHnS + lane;
-  const bool live = s < S;
-  const int64_t sc = live ? s : S - 1;
-  const int64_t Sp = hist_padded(S);
-  if (y == 0) sh_over[lane] = 0;
-  __syncthreads();
-  int cnt[kHistGroups / kHnY];
-  bool over = false;
-#pragma unroll
-  for (int k = 0; k < kHistGroups / kHnY; ++k) {
-    cnt[k] = ovn[(int64_t)(y + k * kHnY) * S + sc];
-    over |= cnt[k] > cap;
-  }
-  if (over) atomicOr(&sh_over[lane], 1);
-  __syncthreads();
-  const bool fits = !sh_over[lane];            // otherwise (an overflow region ran out) the sample is summed cell by cell
-  if (y == 0) {
-    sh_eta[lane] = eta[sc];
-    sh_lam[lane] = lam[sc];
-    sh_done[lane] = live ? done[sc] : 1;
-  }
-  __syncthreads();
-  // second-level bins from the overflow lists (16-bit: a list holds at most cap <= 255 cells and there are 256 lists)
-  if (fits && !sh_done[lane]) {
-#pragma unroll
-    for (int k = 0; k < kHistGroups / kHnY; ++k) {
-      const int64_t base = (int64_t)(y + k * kHnY) * cap;
-      int nres = 0;
-      for (int i = 0; i < cnt[k]; ++i) {
-        const int yy = ov_y[(base + i) * S + sc], rr = ov_r[(base + i) * S + sc];
-        const unsigned ri = (unsigned)(rr - kOv2R0), ni = (unsigned)(yy + rr - kHistKn);
-        if ((unsigned)yy < (unsigned)kHistKy && ri < (unsigned)kOv2 && ni < (unsigned)kOv2) {
-          const int by = yy, br = kHistKy + (int)ri, bn = kHistKy + kOv2 + (int)ni;
-          atomicAdd(&ov2[lane][by >> 1], 1u << ((by & 1) * 16));
-          atomicAdd(&ov2[lane][br >> 1], 1u << ((br & 1) * 16));
-          atomicAdd(&ov2[lane][bn >> 1], 1u << ((bn & 1) * 16));
-        } else {
-          if (nres != i) { ov_y[(base + nres) * S + sc] = yy; ov_r[(base + nres) * S + sc] = rr; }   // this strand's list only
-          ++nres;
-        }
-      }
-      cnt[k] = nres;
-    }
-  }
-  static_assert(kHistGroups == kHnY, "one overflow list per strand (res_pre)");
-  res_pre[lane][y + 1] = (fits && !sh_done[lane]) ? cnt[0] : 0;
-  __syncthreads();
-  if (y == 0) {
-    int run = 0;
-    res_pre[lane][0] = 0;
-    for (int g = 1; g <= kHnY; ++g) { run += res_pre[lane][g]; res_pre[lane][g] = run; }
-  }
-  __syncthreads();
-  if (fits && !sh_done[lane]) {
-    const int64_t base = (int64_t)y * cap;
-    const int q0 = res_pre[lane][y];
-    for (int i = 0; i < cnt[0] && q0 + i < kResLds; ++i) {
-      res_y[lane][q0 + i] = ov_y[(base + i) * S + sc];
-      res_r[lane][q0 + i] = ov_r[(base + i) * S + sc];
-    }
-  }
-  __syncthreads();
-  for (int it = 0; it < max_iter; ++it) {
-    const int dn = sh_done[lane];
-    if (__syncthreads_and(dn)) break;
-    double acc[kFitQ];
-#pragma unroll
-    for (int q = 0; q < kFitQ; ++q) acc[q] = 0.0;
-    if (!dn && !fits) {
-      // rare: the plain per-cell sums (raw psi values, the cell count in acc[5] lets fit_newton_step subtract the
-      // constant terms), the strands sharing the rows
-      const double th = ed_pexp(sh_lam[lane]);
-      const double p = 1.0 / (1.0 + ed_pexp(-sh_eta[lane]));
-      const double a = th * p, b = th * (1.0 - p);
-      edfit::Acc c = {0, 0, 0, 0, 0};
-      double n_cells = 0.0;
-      for (int64_t e = y; e < E; e += kHnY) {
-        const int yy = test[e * rs + sc], rr = ref[e * rs + sc];
-        if (yy + rr > 0) { edfit::accumulate_cell(c, a, b, th, yy, yy + rr); n_cells += 1.0; }
-      }
-      acc[0] = c.ga; acc[1] = c.gb; acc[2] = c.haa; acc[3] = c.hab; acc[4] = c.hbb; acc[5] = n_cells;
-    } else if (!dn) {
-      const double th = ed_pexp(sh_lam[lane]);
-      const double p = 1.0 / (1.0 + ed_pexp(-sh_eta[lane]));
-      const double a = th * p, b = th * (1.0 - p);
-      // The sums are formed from DIFFERENCES psi(a + v) - psi(a) = ln((a + v)/a) + (rest(a + v) - rest(a)) (and the
-      // same for b, a + b and for psi'): the constant terms of the gradient are folded in bin by bin instead of being
-      // subtracted from a sum ~1/phi times larger at the end, which cost 1/phi in relative accuracy (seen as 1e-5
-      // on phi at phi = 5e-5 with the plain sums).
-      double xa, ra, qa, xb, rb, qb, xt, rt, qt;
-      edfit::digamma_trigamma_nolog(a, xa, ra, qa);
-      edfit::digamma_trigamma_nolog(b, xb, rb, qb);
-      edfit::digamma_trigamma_nolog(th, xt, rt, qt);
-      const double ixa = edfit::frcp(xa), ixb = edfit::frcp(xb), ixt = edfit::frcp(xt);
-      // a strand owns a block of consecutive bins of each histogram (first level 4 / 16 / 16, second level 20 / 20)
-      {
-        constexpr int nb = kHistKy / kHnY;
-        const double2 t = hn_block(a + (double)(y * nb), nb, hist + hist_at(0, y * nb, sc, Sp), hist + hist_at(1, y * nb, sc, Sp),
-                                   ov2[lane], y * nb, ixa, ra, qa);
-        acc[0] += t.x; acc[2] += t.y;
-      }
-      {
-        constexpr int nb = kHistKr / kHnY;
-        const double2 t = hn_block(b + (double)(y * nb), nb, hist + hist_at(0, kHistKy + y * nb, sc, Sp),
-                                   hist + hist_at(1, kHistKy + y * nb, sc, Sp), nullptr, 0, ixb, rb, qb);
-        acc[1] += t.x; acc[4] += t.y;
-      }
-      {
-        constexpr int nb = kHistKn / kHnY;
-        const double2 t = hn_block(th + (double)(y * nb), nb, hist + hist_at(0, kHistKy + kHistKr + y * nb, sc, Sp),
-                                   hist + hist_at(1, kHistKy + kHistKr + y * nb, sc, Sp), nullptr, 0, ixt, rt, qt);
-        acc[0] -= t.x; acc[1] -= t.x;
-        acc[2] -= t.y; acc[3] -= t.y; acc[4] -= t.y;
-      }
-      {
-        constexpr int nb = kOv2 / kHnY;
-        const double2 tr = hn_block(b + (double)(kOv2R0 + y * nb), nb, nullptr, nullptr, ov2[lane], kHistKy + y * nb, ixb, rb, qb);
-        acc[1] += tr.x; acc[4] += tr.y;
-        const double2 t = hn_block(th + (double)(kHistKn + y * nb), nb, nullptr, nullptr, ov2[lane], kHistKy + kOv2 + y * nb, ixt, rt, qt);
-        acc[0] -= t.x; acc[1] -= t.x;
-        acc[2] -= t.y; acc[3] -= t.y; acc[4] -= t.y;
-      }
-      // cells beyond the bins: evaluated whole, minus the same constant terms
-      const double ca = edfit::flog(xa * ixt) + (ra - rt), cb = edfit::flog(xb * ixt) + (rb - rt);
-      // the lists differ in length (a few cells each, Poisson): walked list by list, a wave would take as long as its
-      // longest list; instead the strands share the concatenation of the sample's lists round-robin
-      const int n_res = res_pre[lane][kHnY];
-      for (int q = y; q < n_res; q += kHnY) {
-        int yy, rr;
-        if (q < kResLds) {
-          yy = res_y[lane][q]; rr = res_r[lane][q];
-        } else {   // deep data: the rest from the lists themselves (which list? binary search in the prefix)
-          int lo_g = 0, hi_g = kHnY;
-          while (hi_g - lo_g > 1) {
-            const int mid = (lo_g + hi_g) >> 1;
-            if (res_pre[lane][mid] <= q) lo_g = mid; else hi_g = mid;
-          }
-          const int64_t slot = (int64_t)lo_g * cap + (q - res_pre[lane][lo_g]);
-          yy = ov_y[slot * S + sc]; rr = ov_r[slot * S + sc];
-        }
-        edfit::Acc c = {0, 0, 0, 0, 0};
-        edfit::accumulate_cell(c, a, b, th, yy, yy + rr);
-        acc[0] += c.ga - ca; acc[1] += c.gb - cb; acc[2] += c.haa - (qa - qt); acc[3] += c.hab + qt; acc[4] += c.hbb - (qb - qt);
-      }
-    }
-    // acc[5] (the cell count that scales the constant terms in fit_newton_step) stays 0: they are already in
-#pragma unroll
-    for (int q = 0; q < kFitQ; ++q) lds[q][y][lane] = acc[q];
-    __syncthreads();
-    for (int hh = kHnY / 2; hh >= 1; hh >>= 1) {
-      if (y < hh) {
-#pragma unroll
-        for (int q = 0; q < kFitQ; ++q) lds[q][y][lane] += lds[q][y + hh][lane];
-      }
-      __syncthreads();
-    }
-    if (y == 0 && !dn) {
-      double tot[kFitQ];
-#pragma unroll
-      for (int q = 0; q < kFitQ; ++q) tot[q] = lds[q][0][lane];
-      double e = sh_eta[lane], l = sh_lam[lane];
-      int d = 0;
-      fit_newton_step(tot, e, l, d, tol, 1);
-      sh_eta[lane] = e; sh_lam[lane] = l; sh_done[lane] = d;
-    }
-    __syncthreads();
-  }
-  if (y == 0 && live) {
-    eta[s] = sh_eta[lane];
-    lam[s] = sh_lam[lane];
-    done[s] = sh_done[lane];
-  }
+namespace hg2 {
+#define ED_HG_KS 2
+#include "edfit_hist.inc"
+#undef ED_HG_KS
 }
 
 __global__ void k_fit_finish(const double* __restrict__ eta, const double* __restrict__ lam, int64_t S,
@@ -1700,7 +1371,8 @@ struct ed_batch {
   bool ran = false;
   bool fused = false;        // run emissions + Viterbi as ONE kernel (edfused.inc) instead of two overlapped ones
   bool keep_loglik = true;   // fused mode only: also write the [E][3][S] likelihood matrix (the S4 `likelihood` slot)
-  bool fit_hist = true;      // ed_batch_fit: iterate on count histograms (one pass over the counts) instead of per cell
+  int fit_hist = 1;          // ed_batch_fit: 1 = iterate on count histograms (one pass over the counts), geometry picked from
+                             // the data; 8 / 4 / 2 = that geometry (samples per workgroup of k_fit_hist); 0 = per cell
   bool timing = false;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_run_times = false, have_fit_time = false;
@@ -2273,23 +1945,26 @@ struct FitWork {
   double* eta = nullptr;
   double* lam = nullptr;
   int* done = nullptr;
-  uint32_t* hist = nullptr;    // [kHistHalves][kHistK][S] count histograms (k_fit_hist)
-  int32_t* ov_y = nullptr;     // [kHistGroups][ov_cap][S] cells beyond the histogram range, per row group of k_fit_hist
+  uint32_t* hist = nullptr;    // count histograms (k_fit_hist; layout and size depend on the geometry, sized for the largest)
+  int32_t* ov_y = nullptr;     // [lists][cap][S] cells beyond the histogram range, per row group of k_fit_hist
   int32_t* ov_r = nullptr;
-  int32_t* ovn = nullptr;      // [kHistGroups][S] overflow cells of each (row group, sample)
-  int64_t ov_cap = 0;
+  int32_t* ovn = nullptr;      // [lists][S] overflow cells of each (row group, sample)
+  int* depth = nullptr;        // largest per-sample mean total of the columns being fitted (device; k_fit_start)
+  int64_t cap8 = 0, cap4 = 0, cap2 = 0;   // cells per list, by geometry
   int64_t nchunk = 0, S = 0, E_max = 0;
   int alloc_hist()
   {
     if (hist) return ED_OK;
     const int64_t E = E_max;   // sized for the largest fit this workspace serves
-    // per (row group, sample): ~1/3 of the group's rows, at most 255 (the 16-bit second-level bins of k_fit_hnewton count
-    // the cells of the 256 lists of a sample: 256 x 255 < 65536)
-    ov_cap = std::min<int64_t>(255, std::max<int64_t>(8, (E / kHistGroups) / 3 + 1));
-    HIP_TRY(hipMalloc((void**)&hist, (size_t)kHistHalves * kHistK * hist_padded(S) * 4));
-    HIP_TRY(hipMalloc((void**)&ov_y, (size_t)ov_cap * kHistGroups * S * 4));
-    HIP_TRY(hipMalloc((void**)&ov_r, (size_t)ov_cap * kHistGroups * S * 4));
-    HIP_TRY(hipMalloc((void**)&ovn, (size_t)kHistGroups * S * 4));
+    // cells per (row group, sample) list: ~1/3 of the group's rows, and lists x cap < 65536 (the 16-bit second-level bins
+    // of k_fit_hnewton count the cells of all lists of a sample)
+    auto cap_of = [&](int64_t lists) { return std::min<int64_t>(65535 / lists, std::max<int64_t>(8, (E / lists) / 3 + 1)); };
+    cap8 = cap_of(hg8::kHistGroups); cap4 = cap_of(hg4::kHistGroups); cap2 = cap_of(hg2::kHistGroups);
+    const int64_t slots = std::max({cap8 * hg8::kHistGroups, cap4 * hg4::kHistGroups, cap2 * hg2::kHistGroups});
+    HIP_TRY(hipMalloc((void**)&hist, (size_t)hg2::kHistHalves * hg2::kHistK * hg2::hist_padded(S) * 4));
+    HIP_TRY(hipMalloc((void**)&ov_y, (size_t)slots * S * 4));
+    HIP_TRY(hipMalloc((void**)&ov_r, (size_t)slots * S * 4));
+    HIP_TRY(hipMalloc((void**)&ovn, (size_t)hg2::kHistGroups * S * 4));
     return ED_OK;
   }
   int alloc(int64_t E, int64_t S_)
@@ -2304,13 +1979,14 @@ struct FitWork {
     HIP_TRY(hipMalloc((void**)&eta, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&lam, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&done, (size_t)S * 4));
+    HIP_TRY(hipMalloc((void**)&depth, 4));
     return ED_OK;
   }
   void release()
   {
-    void* ptrs[] = {partial, eta, lam, done, hist, ov_y, ov_r, ovn};
+    void* ptrs[] = {partial, eta, lam, done, hist, ov_y, ov_r, ovn, depth};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    partial = eta = lam = nullptr; done = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr;
+    partial = eta = lam = nullptr; done = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr; depth = nullptr;
   }
 };
 
@@ -2323,7 +1999,7 @@ static void fitwork_free(FitWork* w)
 // use_hist: build count histograms once and iterate on them in one launch (needs one test column per sample laid
 // out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
-                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, bool use_hist = false)
+                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0)
 {
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
   const int64_t nch = nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
@@ -2332,15 +2008,25 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
   hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, E >= 65536 ? 16 : 4, w.partial);
-  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done);
+  HIP_TRY(hipMemsetAsync(w.depth, 0, 4, st));
+  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
+  if (use_hist > 1)   // a geometry was asked for: a depth that selects it (tests; fit_hist_geometry)
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.depth, use_hist == 8 ? 1000 : (use_hist == 4 ? 2000 : 4000));
   if (use_hist) {
     if (tcs != 1 || trs != rrs) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
     if (int rc = w.alloc_hist()) return rc;
-    hipLaunchKernelGGL(k_fit_hist, dim3((unsigned)((((S + kHistSamples - 1) / kHistSamples * kHistHalves + 7) / 8) * 8)), dim3(kHistBlock), 0, st, d_test, d_ref,
-                       rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap);
-    hipLaunchKernelGGL(k_fit_hnewton, dim3((unsigned)((S + kHnS - 1) / kHnS)), dim3(kHnS, kHnY), 0, st, w.hist, w.ov_y, w.ov_r, w.ovn, w.ov_cap, S,
-                       w.eta, w.lam, w.done, 100, 1e-9,   // iterations are cheap here: converge tightly
-                       d_test, d_ref, rrs, E);
+    // one launch per geometry; the device flag w.depth lets exactly one of each kind do the work (no host round trip)
+#define ED_FIT_HIST(NS, CAP)                                                                                                       \
+    hipLaunchKernelGGL(NS::k_fit_hist, dim3((unsigned)((((S + NS::kHistSamples - 1) / NS::kHistSamples * NS::kHistHalves + 7) / 8) * 8)), \
+                       dim3(NS::kHistBlock), 0, st, d_test, d_ref, rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, CAP, w.depth);
+    ED_FIT_HIST(hg8, w.cap8) ED_FIT_HIST(hg4, w.cap4) ED_FIT_HIST(hg2, w.cap2)
+#undef ED_FIT_HIST
+#define ED_FIT_NEWTON(NS, CAP)                                                                                                     \
+    hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
+                       w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */,  \
+                       d_test, d_ref, rrs, E, w.depth);
+    ED_FIT_NEWTON(hg8, w.cap8) ED_FIT_NEWTON(hg4, w.cap4) ED_FIT_NEWTON(hg2, w.cap2)
+#undef ED_FIT_NEWTON
     hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
     HIP_TRY(hipGetLastError());
     return ED_OK;
@@ -2403,7 +2089,8 @@ ED_EXPORT int ed_batch_set_fused(ed_batch* b, int fused)
 ED_EXPORT int ed_batch_set_fit_histograms(ed_batch* b, int on)
 {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
-  b->fit_hist = on != 0;
+  if (on != 0 && on != 1 && on != 2 && on != 4 && on != 8) return ed_fail(ED_ERR_INVALID, "ed_batch_set_fit_histograms: 0, 1 (automatic), or a geometry 8 / 4 / 2");
+  b->fit_hist = on;
   return ED_OK;
 }
 

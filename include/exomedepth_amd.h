@@ -128,7 +128,9 @@ int ed_batch_fit(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, d
                  void* stream);
 /* How ed_batch_fit iterates: 1 (default) on per-sample count histograms built in one pass over the counts
  * (every Newton iteration then costs ~9 000 digamma evaluations per sample instead of 3 x n_exons); 0 per cell on
- * every pass.  Same maximum; the two differ by summation order only. */
+ * every pass.  Same maximum; the two differ by summation order only.  The histograms come in three geometries (unit
+ * bins up to 4096 / 8192 / 16384 for the reference and total counts), picked on the device from the batch's depth;
+ * on = 8, 4 or 2 asks for one of them (what the tests do), 1 leaves the choice to the data. */
 int ed_batch_set_fit_histograms(ed_batch* batch, int on);
 /* The same fit on every `by`-th exon only (exons 0, by, 2*by, ...): the scalar form of subset.for.speed,
  * reference R/class_definition.R:107-113, where by = floor(n_exons / subset.for.speed).  by = 1 is ed_batch_fit. */

@@ -28,12 +28,14 @@ def test_device_digamma_trigamma(edlib, oracle):
     assert np.max(np.abs(got1 - psi1) / np.abs(psi1)) < 5e-15
 
 
-def _fit_case(edlib, oracle, E, S, seed, **kw):
+def _fit_case(edlib, oracle, E, S, seed, geometry=None, **kw):
     from exomedepth_amd import synth
     chrom_off, start, end = synth.exon_design(E, 4, seed)
     test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=5, **kw)
     plan = edlib.Plan(chrom_off, start, end)
     batch = edlib.Batch(plan, S)
+    if geometry is not None:
+        batch.set_fit_histograms(geometry)
     dphi = edlib.DeviceArray(np.zeros(S))
     dexp = edlib.DeviceArray(np.zeros(S))
     batch.fit(test, ref, dphi, dexp)
@@ -139,6 +141,22 @@ def test_fit_slow_start_case(edlib, oracle, hist):
     # a + b = 3 200 here: the digamma differences of the gradient cancel ~4 digits more than at phi ~ 5e-3, and the
     # binary64 digamma (5e-15 relative) shows: 1e-8 relative on phi observed, 1e-7 asserted
     assert np.all(np.abs(gphi - ophi) < 1e-7 * ophi) and np.all(np.abs(gexp - op) < FIT_REL_TOL * op)
+
+
+@pytest.mark.parametrize("geometry", [8, 4, 2])
+@pytest.mark.parametrize("depth", [60.0, 250.0, 900.0])
+def test_fit_every_histogram_geometry(edlib, oracle, geometry, depth):
+    """The three histogram geometries (8 / 4 / 2 samples per workgroup of k_fit_hist: unit bins to 4096 / 8192 / 16384)
+    are picked from the data's depth; here each is forced on shallow, medium and deep data, so that every one of them
+    meets counts inside its bins, in the second-level bins, in the lists, and (deep data on the small geometry) lists
+    that run out.  S = 13: not a multiple of any workgroup's sample count."""
+    _fit_case(edlib, oracle, E=7000, S=13, seed=int(depth) + geometry, geometry=geometry, mean_depth=depth)
+
+
+def test_fit_geometry_follows_depth(edlib, oracle):
+    """Automatic choice: same answers (checked against the MLE) whichever geometry the depth selects."""
+    for depth in (100.0, 260.0, 500.0):
+        _fit_case(edlib, oracle, E=5000, S=9, seed=900 + int(depth), mean_depth=depth)
 
 
 def test_fit_counts_beyond_the_histogram_range(edlib, oracle):
