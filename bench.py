@@ -236,8 +236,8 @@ def main():
                          "kernel_cells_per_s": (E * S / t_emit if t_emit else 0.0),
                          "algorithmic_bytes_per_cell_with_likelihood_matrix": 33,
                          "note": "FP64-VALU-bound kernel (no MFMA applies; SURVEY.md 0.5): the HBM roofline is the formal "
-                                 "denominator. rocprofv3 PMC (profiles/r01_i_pmc_SQ.csv, r01_i_pmc_GRBM_GUI_ACTIVE.csv): 1253 VALU "
-                                 "instructions per cell at 84% VALU-busy. traffic exceeds the 9 B/cell figure because the "
+                                 "denominator. rocprofv3 PMC (profiles/r01_k_pmc_SQ.csv, r01_k_pmc_GRBM_GUI_ACTIVE.csv): 1253 VALU "
+                                 "instructions per cell at 85% VALU-busy (the kernel alone runs at 8.8 ms per step; the Viterbi kernels sharing the SIMDs cost it 1.2 ms, DESIGN.md 4.2). traffic exceeds the 9 B/cell figure because the "
                                  "kernel materialises the [E][3][S] f64 likelihood matrix (the reference's S4 `likelihood` "
                                  "slot: 24 B/cell written once, read once by the Viterbi; 33 B/cell algorithmic in that form, "
                                  "SURVEY.md 8d) and gathers tabulated terms (L2-resident tables; the misses are counted with "

@@ -11,10 +11,12 @@
 //   k_calls_fill      per chain: writes the call records (src/hmm.cpp:104-126, R/class_definition.R:371-372,:409-410)
 //   k_call_info       decoration of the calls (R/class_definition.R:379-405)
 //   k_fit_*           per-sample beta-binomial fit (aod::betabin's role, R/class_definition.R:118):
-//                     k_fit_moments/start, k_fit_hist + k_fit_hnewton (histogram form), k_fit_accum/update (per cell)
+//                     k_fit_moments/start, k_fit_accum/update (per cell)
+//   edfit_hist.inc    k_fit_hist + k_fit_hnewton: the histogram form of that fit, in three geometries (hg8 / hg4 / hg2)
 //   edfused.inc       k_emit_viterbi: emissions + Viterbi in one kernel (optional mode)
 //   edrefset.inc      select.reference.set (R/optimize_reference_set.R:53-148)
 //   edbins.inc        phi.bins > 1 (R/class_definition.R:120-147)
+//   edcov.inc         covariates in the mean model (data + formula, R/class_definition.R:86-118)
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (contraction off is part of the contract:
 // the arithmetic must match the CPU checker bit for bit).
 #include <hip/hip_runtime.h>
@@ -1248,10 +1250,10 @@ k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, doub
 // The gradient and Hessian of the log-likelihood are sums over cells of psi / psi' at a + y, b + (n - y) and
 // a + b + n: functions of ONE count each.  So they are sums over the distinct values of y, n - y and n weighted by
 // how often each value occurs in the sample -- three histograms per sample, built in ONE pass over the counts
-// (k_fit_hist: LDS-privatised, 4 samples per workgroup).  Every Newton iteration then costs ~9 000 digamma
-// evaluations per sample instead of 3 x n_exons, and all iterations run inside one launch (k_fit_hnewton).  Cells
-// with a count beyond the histogram range go to a per-sample overflow list and are evaluated one by one; a
-// sample whose list overflows, or that has not converged, is finished by the per-cell kernels above.
+// (k_fit_hist: LDS-privatised, 8 / 4 / 2 samples per workgroup).  Every Newton iteration then costs one reciprocal per
+// bin instead of 3 x n_exons digamma evaluations, and all iterations run inside one launch (k_fit_hnewton).  Cells
+// with a count beyond the histogram range go to per-sample overflow lists (second-level bins in LDS, then one by
+// one); a sample whose list runs out is summed cell by cell inside the same launch.
 // (Sums are grouped by value instead of by exon: the result differs from the per-cell path by rounding only.)
 // Which geometry serves a batch: depth = the largest per-sample mean total count n (k_fit_start).  The unit bins plus
 // the second level of k_fit_hnewton reach n = 9216 / 13312 / 21504; they should cover ~5 x the mean (the synthetic

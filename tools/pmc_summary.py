@@ -1,11 +1,12 @@
 """Summarise a rocprofv3 counter_collection csv: per kernel of this library, mean counter value per launch."""
-import collections, csv, sys
+import collections, csv, re, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "anonymous namespace)::k_" not in k:
+    m = re.match(r"\(anonymous namespace\)::((?:hg\d::)?k_\w+)", k)   # hgN:: = a histogram geometry of the fit
+    if not m:
         continue
-    name = k.split("::")[1].split("(")[0]
+    name = m.group(1)
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("kernel,counter,launches,mean_per_launch")
 for n in sorted(acc):

@@ -17,7 +17,7 @@ rows = list(csv.reader(open(out + "/ks_kernel_stats.csv")))
 with open(out + "/kernel_stats.csv", "w", newline="") as f:
     w = csv.writer(f); w.writerow(rows[0])
     for r in rows[1:]:
-        if r[0].startswith("(anonymous namespace)::k_"): w.writerow(r)
+        if r[0].startswith("(anonymous namespace)::k_") or r[0].startswith("(anonymous namespace)::hg"): w.writerow(r)
 PY
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   N=$(echo $C | cut -d' ' -f1)
