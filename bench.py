@@ -43,6 +43,30 @@ def pmc_traffic(kernel, n_launch):
     return per_step / n_launch, os.path.basename(files[-1])
 
 
+def pmc_valu(kernel, cells_per_step):
+    """VALU figures of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_SQ.csv, *_pmc_GRBM_GUI_ACTIVE.csv,
+    summarised per launch by tools/pmc_summary.py): wave-instructions per cell and the fraction of SIMD issue cycles spent
+    on them, SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs) / 1024 SIMDs.  None if no profile is committed."""
+    import csv, glob
+    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_SQ.csv")))
+    gr = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_GRBM_GUI_ACTIVE.csv")))
+    if not sq or not gr:
+        return None
+    def load(f):
+        return {(r["kernel"], r["counter"]): (float(r["mean_per_launch"]), int(r["launches"])) for r in csv.DictReader(open(f))}
+    a, b = load(sq[-1]), load(gr[-1])
+    try:
+        insts, n = a[(kernel, "SQ_INSTS_VALU")]
+        active = a[(kernel, "SQ_ACTIVE_INST_VALU")][0]
+        gui = b[(kernel, "GRBM_GUI_ACTIVE")][0]
+    except KeyError:
+        return None
+    steps = 3   # tools/profile_round.sh: --steps 2 --warmup 1
+    return {"valu_wave_instructions_per_cell": insts * n / steps / (cells_per_step / 64.0),
+            "valu_busy": active * 4.0 / (gui / 8.0) / 1024.0,
+            "source": [os.path.basename(sq[-1]), os.path.basename(gr[-1])]}
+
+
 def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit, allcores=False, test_all=None, p_all=None, phi_all=None):
     """The CPU checker's libm flavour (bit-identical to the reference's compiled special functions)
     timed on one host core over a bounded sample of the same workload."""
@@ -235,6 +259,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * E * S / n_launch,
                          "kernel_cells_per_s": (E * S / t_emit if t_emit else 0.0),
                          "algorithmic_bytes_per_cell_with_likelihood_matrix": 33,
+                         "valu": pmc_valu("k_emit_viterbi" if args.fused else "k_emit_batch", float(E) * S),
                          "note": "FP64-VALU-bound kernel (no MFMA applies; SURVEY.md 0.5): the HBM roofline is the formal "
                                  "denominator. rocprofv3 PMC (profiles/r01_k_pmc_SQ.csv, r01_k_pmc_GRBM_GUI_ACTIVE.csv): 1253 VALU "
                                  "instructions per cell at 85% VALU-busy (the kernel alone runs at 8.8 ms per step; the Viterbi kernels sharing the SIMDs cost it 1.2 ms, DESIGN.md 4.2). traffic exceeds the 9 B/cell figure because the "
