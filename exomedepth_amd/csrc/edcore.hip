@@ -1259,8 +1259,18 @@ k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, doub
 // the second level of k_fit_hnewton reach n = 9216 / 13312 / 21504; they should cover ~5 x the mean (the synthetic
 // design's log-normal exon depths put 99.5 % of the cells below that).  Never a matter of correctness: cells beyond
 // the bins are evaluated one by one.
-__global__ void k_set_int(int* p, int v) { *p = v; }
 __host__ __device__ __forceinline__ int fit_hist_geometry(int depth) { return depth <= 1843 ? 8 : (depth <= 2662 ? 4 : 2); }
+// Which of the launched geometries runs: fit_columns launches the one the PREVIOUS fit's depth points to (all three
+// the first time), `launched` says which (bit 0 / 1 / 2 = 8 / 4 / 2 samples per workgroup).  If the data's own choice
+// is among them it runs; if not (the depth changed between calls) the launched geometry with the longest bins does --
+// every geometry gives the same answer, only the time differs.
+__host__ __device__ __forceinline__ int fit_hist_bit(int ks) { return ks == 8 ? 1 : (ks == 4 ? 2 : 4); }
+__device__ __forceinline__ bool fit_hist_runs(int depth, int launched, int mine)
+{
+  const int sel = fit_hist_geometry(depth);
+  if (launched & fit_hist_bit(sel)) return mine == sel;
+  return mine == ((launched & 4) ? 2 : ((launched & 2) ? 4 : 8));
+}
 
 namespace hg8 {
 #define ED_HG_KS 8
@@ -1952,6 +1962,7 @@ struct FitWork {
   int32_t* ov_r = nullptr;
   int32_t* ovn = nullptr;      // [lists][S] overflow cells of each (row group, sample)
   int* depth = nullptr;        // largest per-sample mean total of the columns being fitted (device; k_fit_start)
+  int* h_depth = nullptr;      // the same, copied back after every fit (pinned host memory): next call's hint, -1 = none yet
   int64_t cap8 = 0, cap4 = 0, cap2 = 0;   // cells per list, by geometry
   int64_t nchunk = 0, S = 0, E_max = 0;
   int alloc_hist()
@@ -1982,12 +1993,16 @@ struct FitWork {
     HIP_TRY(hipMalloc((void**)&lam, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&done, (size_t)S * 4));
     HIP_TRY(hipMalloc((void**)&depth, 4));
+    HIP_TRY(hipHostMalloc((void**)&h_depth, 4, hipHostMallocDefault));
+    *h_depth = -1;
     return ED_OK;
   }
   void release()
   {
     void* ptrs[] = {partial, eta, lam, done, hist, ov_y, ov_r, ovn, depth};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h_depth) (void)hipHostFree(h_depth);
+    h_depth = nullptr;
     partial = eta = lam = nullptr; done = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr; depth = nullptr;
   }
 };
@@ -2012,21 +2027,26 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, E >= 65536 ? 16 : 4, w.partial);
   HIP_TRY(hipMemsetAsync(w.depth, 0, 4, st));
   hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
-  if (use_hist > 1)   // a geometry was asked for: a depth that selects it (tests; fit_hist_geometry)
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, w.depth, use_hist == 8 ? 1000 : (use_hist == 4 ? 2000 : 4000));
   if (use_hist) {
     if (tcs != 1 || trs != rrs) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
     if (int rc = w.alloc_hist()) return rc;
-    // one launch per geometry; the device flag w.depth lets exactly one of each kind do the work (no host round trip)
+    // Which geometries to launch: the one asked for (tests), else the one the previous fit's depth points to, else
+    // (first fit of this workspace) all three.  The kernels themselves decide which of the launched ones runs, from
+    // THIS fit's depth (fit_hist_runs) -- no host round trip, and a stale hint costs time, never correctness.
+    const int hint = *(volatile int*)w.h_depth;
+    const int launched = use_hist > 1 ? fit_hist_bit(use_hist) : (hint < 0 ? 7 : fit_hist_bit(fit_hist_geometry(hint)));
+    HIP_TRY(hipMemcpyAsync(w.h_depth, w.depth, 4, hipMemcpyDeviceToHost, st));
 #define ED_FIT_HIST(NS, CAP)                                                                                                       \
-    hipLaunchKernelGGL(NS::k_fit_hist, dim3((unsigned)((((S + NS::kHistSamples - 1) / NS::kHistSamples * NS::kHistHalves + 7) / 8) * 8)), \
-                       dim3(NS::kHistBlock), 0, st, d_test, d_ref, rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, CAP, w.depth);
+    if (launched & fit_hist_bit(NS::kHistSamples))                                                                                 \
+      hipLaunchKernelGGL(NS::k_fit_hist, dim3((unsigned)((((S + NS::kHistSamples - 1) / NS::kHistSamples * NS::kHistHalves + 7) / 8) * 8)), \
+                         dim3(NS::kHistBlock), 0, st, d_test, d_ref, rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, CAP, w.depth, launched);
     ED_FIT_HIST(hg8, w.cap8) ED_FIT_HIST(hg4, w.cap4) ED_FIT_HIST(hg2, w.cap2)
 #undef ED_FIT_HIST
 #define ED_FIT_NEWTON(NS, CAP)                                                                                                     \
-    hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
-                       w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */,  \
-                       d_test, d_ref, rrs, E, w.depth);
+    if (launched & fit_hist_bit(NS::kHistSamples))                                                                                 \
+      hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
+                         w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */, \
+                         d_test, d_ref, rrs, E, w.depth, launched);
     ED_FIT_NEWTON(hg8, w.cap8) ED_FIT_NEWTON(hg4, w.cap4) ED_FIT_NEWTON(hg2, w.cap2)
 #undef ED_FIT_NEWTON
     hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);

@@ -159,6 +159,28 @@ def test_fit_geometry_follows_depth(edlib, oracle):
         _fit_case(edlib, oracle, E=5000, S=9, seed=900 + int(depth), mean_depth=depth)
 
 
+def test_fit_geometry_hint_is_only_a_hint(edlib, oracle):
+    """A batch launches the histogram geometry its PREVIOUS fit's depth points to; which of the launched kernels runs is
+    decided on the device from the current data.  Shallow, then deep, then deep, then shallow data through one batch:
+    the second and fourth fits run on a geometry chosen for other data -- same answers."""
+    from exomedepth_amd import synth
+    from exomedepth_amd._lib import check, lib
+    E, S = 6000, 7
+    chrom_off, start, end = synth.exon_design(E, 3, 77)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    dphi = edlib.DeviceArray(np.zeros(S)); dexp = edlib.DeviceArray(np.zeros(S))
+    for k, depth in enumerate((60.0, 700.0, 700.0, 60.0)):
+        test, ref, _, _, _ = synth.counts_numpy(chrom_off, S, 770 + k, n_segments=4, mean_depth=depth)
+        batch.fit(test, ref, dphi, dexp)
+        check(lib().ed_synchronize(None))
+        gphi, gexp = dphi.to_host(), dexp.to_host()
+        for s in range(S):
+            ophi, op, _, _ = oracle.fit_mle(test[:, s], ref[:, s])
+            assert abs(gphi[s] - ophi) / ophi < FIT_REL_TOL and abs(gexp[s] - op) / op < FIT_REL_TOL, (k, depth, s, gphi[s], ophi)
+    batch.close(); plan.close()
+
+
 def test_fit_counts_beyond_the_histogram_range(edlib, oracle):
     """Deep data: every reference count lies beyond the 4096 bins, the overflow regions run out, and the Newton
     kernel sums those samples cell by cell (same launch).  A moderately deep case uses bins and overflow lists together."""
