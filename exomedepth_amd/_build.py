@@ -45,5 +45,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# Diagnostic variants of the library (same sources, different code generation); never loaded by the package itself.
+VARIANTS = {"coldinline": ["-DED_COLD_INLINE"]}
+
+
+def variant_path(name):
+    return os.path.join(HERE, "libedcore_%s.so" % name)
+
+
+def build_variant(name, force=False, verbose=False):
+    out = variant_path(name)
+    if not force and os.path.exists(out) and not stale() and os.path.getmtime(out) >= os.path.getmtime(LIB):
+        return out
+    cmd = [hipcc()] + FLAGS + VARIANTS[name] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(" ".join(cmd)); print(r.stdout); print(r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed building %s" % out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -27,6 +27,11 @@ class EdCallInfo(C.Structure):
                 ("reads_ratio", C.c_double)]
 
 
+class EdEmitMismatch(C.Structure):
+    _fields_ = [("exon", C.c_int64), ("sample", C.c_int64), ("state", C.c_int32), ("observed", C.c_int32), ("total", C.c_int32),
+                ("pad_", C.c_int32), ("got", C.c_double), ("want", C.c_double)]
+
+
 class EdCall(C.Structure):
     _fields_ = [("sample", C.c_int32), ("chrom", C.c_int32), ("start_exon", C.c_int32), ("end_exon", C.c_int32),
                 ("type", C.c_int32), ("nexons", C.c_int32)]
@@ -70,6 +75,7 @@ SYMBOLS = [
     ("ed_batch_copy_call_info", C.c_int, [_vp, _vp, _i64]),
     ("ed_batch_copy_path", C.c_int, [_vp, _vp]),
     ("ed_batch_copy_loglik", C.c_int, [_vp, _vp]),
+    ("ed_batch_verify_emissions", C.c_int, [_vp, _vp, _vp, _vp, _vp, _dbl, C.POINTER(_i64), C.POINTER(_i64), _vp, _i64]),
     ("ed_batch_enable_timing", C.c_int, [_vp, C.c_int]),
     ("ed_batch_stage_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("ed_select_reference_set", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),

@@ -370,6 +370,23 @@ class Batch:
         check(lib().ed_batch_copy_loglik(self.handle, _ptr(out)))
         return out
 
+    def verify_emissions(self, test, ref, phi, expected, mixture=1.0, cap=16):
+        """Device-side self-check of the last run()'s likelihood matrix: every cell re-evaluated with the reference's own
+        per-cell loop (no hoisting, tables or binning) and compared bit for bit.  Arguments: what run() was given.
+        Returns (values compared, values that differ, first mismatches as a list of dicts)."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi, np.float64, keep)
+        pe = _device_pointer(expected, np.float64, keep)
+        first = (_lib.EdEmitMismatch * max(int(cap), 1))()
+        ncmp, nbad = C.c_int64(0), C.c_int64(0)
+        check(lib().ed_batch_verify_emissions(self.handle, pt, pr, pp, pe, float(mixture), C.byref(ncmp), C.byref(nbad),
+                                              C.cast(first, C.c_void_p), int(cap)))
+        rec = [{f: getattr(first[i], f) for f in ("exon", "sample", "state", "observed", "total", "got", "want")}
+               for i in range(min(int(cap), nbad.value))]
+        return ncmp.value, nbad.value, rec
+
     def device_pointers(self):
         L = lib()
         return {"loglik": L.ed_batch_loglik(self.handle), "path": L.ed_batch_path(self.handle),

@@ -15,6 +15,15 @@
 #include <hip/hip_runtime.h>
 #include "ed_pmath.h"
 
+// Cold functions (ranges the path rarely or never reaches) are kept out of line so that the hot routes stay small.
+// -DED_COLD_INLINE builds the diagnostic variant of the library in which they are inlined instead
+// (tools/soak_emission.py --variant coldinline: same bits expected, different code generation).
+#if defined(ED_COLD_INLINE)
+#define EDSF_COLD __forceinline__
+#else
+#define EDSF_COLD __noinline__
+#endif
+
 namespace edsf {
 
 // ---- constants, spelled as the reference spells them (src/gsl_math.h, src/gsl_machine.h) ----
@@ -160,7 +169,7 @@ __device__ __forceinline__ double lngamma_lanczos(double x, const double* LT = n
 }
 
 // (2,2) Pade + correction for log Gamma(1+eps), log Gamma(2+eps), |eps| < 0.01 (src/VP_gamma.c:928-980)
-__device__ __noinline__ double lngamma_pade(double eps, int two)
+__device__ EDSF_COLD double lngamma_pade(double eps, int two)
 {
   const double n1 = two ? 1.000895834786669227164446568 : -1.0017419282349508699871138440;
   const double n2 = two ? 4.209376735287755081642901277 : 1.7364839209922879823280541733;
@@ -182,7 +191,7 @@ __device__ __noinline__ double lngamma_pade(double eps, int two)
 
 // log Gamma for 0 < x < 0.5 (cold): small-x series (:761-787) or reflection (:1180-1199 / :1244-1276).
 // zform selects sin(pi*(1-x)) (gsl_sf_lngamma_e, used by Gamma*) or sin(pi*x) (gsl_sf_lngamma_sgn_e).
-__device__ __noinline__ double lngamma_below_half(double x, bool zform)
+__device__ EDSF_COLD double lngamma_below_half(double x, bool zform)
 {
   if (x < 0.02) {
     const double c1 = -0.07721566490153286061, c2 = -0.01094400467202744461, c3 = 0.09252092391911371098,
@@ -228,7 +237,7 @@ __device__ __forceinline__ double gammastar_large(double x)
 }
 
 // Gamma*(x) for 0 < x < 10 (src/VP_gamma.c:1340-1362): less common on the path, kept out of line
-__device__ __noinline__ double gammastar_small(double x)
+__device__ EDSF_COLD double gammastar_small(double x)
 {
   if (x < 0.5) {
     const double lg = lngamma_pos(x, true);
@@ -271,7 +280,7 @@ __device__ __forceinline__ double log1plusx_ratio(double x)
 //                                   reflection formula; a negative shape parameter needs phi > 1, which is
 //                                   outside the model's domain (negative integers are NaN in the reference too).
 // *flag is set to 1: in all these cases the reference raises a GSL error (two printed lines per event).
-__device__ __noinline__ double lnbeta_cold(double x, double y, int* flag)
+__device__ EDSF_COLD double lnbeta_cold(double x, double y, int* flag)
 {
   *flag = 1;
   if (x == 0.0 || y == 0.0) return ed_pm_nan();

@@ -354,6 +354,59 @@ k_emit_rows(const double* __restrict__ phi, const double* __restrict__ expected,
   if (nflag) atomicAdd(nerr, (unsigned long long)nflag);
 }
 
+// Self-check of the batched emissions (ed_batch_verify_emissions): every cell is evaluated a second time with the
+// straight per-cell arithmetic of the reference's loop -- six log-Betas per cell as src/CNV_estimate.cpp:71-81 has
+// them, shape parameters recomputed from (phi, expected), no hoisted constants, no tables, no binning, no LDS -- and
+// compared bit for bit with what k_emit_batch left in the likelihood matrix, on the device.  NaN matches NaN.
+// counters[0] = mismatching values, counters[1] = values compared; the first `cap` mismatches are recorded.
+__global__ void __launch_bounds__(kEmitBlock)
+k_emit_verify(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ phi,
+              const double* __restrict__ expected, double mixture, int64_t E, int64_t S, const double* __restrict__ loglik,
+              unsigned long long* __restrict__ counters, ed_emit_mismatch* __restrict__ first, int64_t cap)
+{
+  const int64_t s_raw = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t e_raw = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (kEmitBlock / 64) + (threadIdx.x >> 6);
+  const bool live = s_raw < S && e_raw < E;      // idle lanes shadow cell (0, 0) and count nothing
+  const int64_t s = live ? s_raw : 0, e = live ? e_raw : 0;
+  const double ex = expected[s];
+  const double sd = __builtin_sqrt((phi[s] * ex) * (1. - ex));
+  double ep[3];
+  state_props(ex, mixture, ep);
+  const int32_t obs = test[e * S + s];
+  const int32_t tot = obs + ref[e * S + s];
+  int bad = 0;
+#pragma unroll 1
+  for (int st = 0; st < 3; ++st) {
+    double a1, a2;
+    shape_params(ep[st], sd, a1, a2);
+    int f1 = 0, f2 = 0;
+    const double v1 = edsf::lnbeta(a1 + (double)obs, (a2 + (double)tot) - (double)obs, &f1);
+    const double v0 = edsf::lnbeta(a1, a2, &f2);
+    const double want = v1 - v0;
+    const double got = loglik[(e * 3 + st) * S + s];
+    const bool same = (__double_as_longlong(want) == __double_as_longlong(got)) || (want != want && got != got);
+    if (live && !same) {
+      ++bad;
+      const unsigned long long k = atomicAdd(&counters[2], 1ull);
+      if ((int64_t)k < cap) {
+        ed_emit_mismatch m;
+        m.exon = e; m.sample = s; m.state = st; m.observed = obs; m.total = tot;
+        m.got = got; m.want = want;
+        first[k] = m;
+      }
+    }
+  }
+  // one pair of atomics per wave
+  const unsigned long long nlive = __popcll(__ballot(live));
+  int wsum = bad;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+  if ((threadIdx.x & 63) == 0) {
+    if (wsum) atomicAdd(&counters[0], (unsigned long long)wsum);
+    if (nlive) atomicAdd(&counters[1], 3ull * nlive);
+  }
+}
+
 // ---- Viterbi --------------------------------------------------------------------------------
 
 // One forward step (src/hmm.cpp:68-88).  v[] are the previous scores, e[] the three emissions in HMM
@@ -2228,6 +2281,36 @@ ED_EXPORT int ed_batch_copy_loglik(ed_batch* b, double* host_loglik)
   if ((b->fused && !b->keep_loglik) || !b->d_loglik)
     return ed_fail(ED_ERR_STATE, "the likelihood matrix is not kept (ed_batch_keep_loglik)");
   HIP_TRY(hipMemcpy(host_loglik, b->d_loglik, (size_t)b->plan->E * 3 * b->S * 8, hipMemcpyDeviceToHost));
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
+                                        const double* d_expected, double mixture, int64_t* n_compared, int64_t* n_mismatch,
+                                        ed_emit_mismatch* first, int64_t cap)
+{
+  if (int rc = batch_ready(b)) return rc;
+  if (!d_test || !d_ref || !d_phi || !d_expected || !n_compared || !n_mismatch || cap < 0 || (cap > 0 && !first))
+    return ed_fail(ED_ERR_INVALID, "ed_batch_verify_emissions: bad arguments");
+  if ((b->fused && !b->keep_loglik) || !b->d_loglik)
+    return ed_fail(ED_ERR_STATE, "ed_batch_verify_emissions: the likelihood matrix is not kept (ed_batch_keep_loglik)");
+  const int64_t E = b->plan->E, S = b->S;
+  *n_compared = 0; *n_mismatch = 0;
+  if (E == 0) return ED_OK;
+  DevBuf dcnt, dfirst;
+  HIP_TRY(dcnt.alloc(24)); HIP_TRY(dfirst.alloc((size_t)cap * sizeof(ed_emit_mismatch)));
+  HIP_TRY(hipMemsetAsync(dcnt.p, 0, 24, b->stream));
+  const int64_t eblk = (E + kEmitBlock / 64 - 1) / (kEmitBlock / 64);
+  hipLaunchKernelGGL(k_emit_verify, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535), (unsigned)((eblk + 65534) / 65535)),
+                     dim3(kEmitBlock), 0, b->stream, d_test, d_ref, d_phi, d_expected, mixture, E, S, b->d_loglik,
+                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  unsigned long long c[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpy(c, dcnt.p, 24, hipMemcpyDeviceToHost));
+  *n_mismatch = (int64_t)c[0];
+  *n_compared = (int64_t)c[1];
+  const int64_t k = std::min<int64_t>((int64_t)c[2], cap);
+  if (k > 0) HIP_TRY(hipMemcpy(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), hipMemcpyDeviceToHost));
   return ED_OK;
 }
 

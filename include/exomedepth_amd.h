@@ -206,6 +206,24 @@ int ed_batch_copy_call_info(ed_batch* batch, ed_call_info* host_info, int64_t ca
 int ed_batch_copy_path(ed_batch* batch, uint8_t* host_path /* [n_exons][n_samples] */);
 int ed_batch_copy_loglik(ed_batch* batch, double* host_loglik /* [n_exons][3][n_samples] */);
 
+/* Self-check of the emissions of the last ed_batch_run (default model, two-kernel mode or fused mode with the
+ * matrix kept).  ed_batch_run evaluates a cell's three log-likelihoods through per-sample hoisted constants, per-sample
+ * tables and route binning; this entry evaluates every cell again ON THE DEVICE with the reference's own loop
+ * (src/CNV_estimate.cpp:71-81: shape parameters from (phi, expected), six log-Betas, nothing hoisted or tabulated)
+ * and compares the bits with the likelihood matrix -- no host round trip, so whole batches can be soaked.
+ * Inputs are the DEVICE arrays the run was given.  n_compared / n_mismatch count values (3 per cell); the first
+ * `cap` mismatches are returned in `first` (may be NULL with cap = 0).  Synchronous. */
+typedef struct {
+  int64_t exon, sample;
+  int32_t state;            /* 0 deletion, 1 normal, 2 duplication */
+  int32_t observed, total;
+  int32_t pad_;
+  double got, want;         /* the likelihood matrix's value / the per-cell evaluation */
+} ed_emit_mismatch;
+int ed_batch_verify_emissions(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
+                              const double* d_expected, double mixture, int64_t* n_compared, int64_t* n_mismatch,
+                              ed_emit_mismatch* first, int64_t cap);
+
 /* Per-stage device times of the last ed_batch_run / ed_batch_fit, measured with HIP events on the
  * stream the kernels were launched on (enable before the run; costs nothing when disabled).
  * ms[]: 0 sample constants, 1 emissions, 2 Viterbi (forward + trace-back + call count),

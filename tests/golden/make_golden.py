@@ -34,8 +34,28 @@ def around(vals, rel=(1e-15, 1e-12, 1e-6, 1e-3)):
     return np.array(out)
 
 
+def survey_probe_fixture():
+    """config1_survey_probe.json: the facts SURVEY.md 8c (G4) recorded from the reference's compiled C for Exome1 vs
+    Exome2+3+4 with (eta, phi) = (-1.36727, 0.0049568) -- those are `reference_facts`, typed in from the survey, not
+    computed here -- and, beside them, the checker's call table for exactly those parameters (`calls_regression`)."""
+    import math
+    d = np.load(os.path.join(HERE, "exomecount_chr1.npz"))
+    counts = d["counts"]
+    test = counts[:, 0].astype(np.int32)
+    ref = counts[:, 1:].sum(axis=1).astype(np.int32)
+    facts = {"eta": -1.36727, "phi": 0.0049568, "padded_observations": 26549, "state_counts_padded": [26320, 121, 108], "n_calls": 25}
+    p = 1.0 / (1.0 + math.exp(-facts["eta"]))
+    L, _ = eo.get_loglike_matrix(facts["phi"], p, test + ref, test, 1.0, eo.LIBM)
+    path, calls = eo.callcnvs(L, np.array([0, test.size], np.int32), d["start"], d["end"])
+    json.dump({"reference_facts": facts, "calls_regression": calls.astype(np.int64).tolist()},
+              open(os.path.join(HERE, "config1_survey_probe.json"), "w"), indent=1)
+
+
 def main():
     eo.build()
+    if "--survey-probe-only" in sys.argv:
+        survey_probe_fixture()
+        return
     assert eo.ref_available(), "oracle/_ref/libgslsf_ref.so missing (needs /root/reference)"
     rng = np.random.default_rng(20250620)
     g = {}
@@ -91,6 +111,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "config1_expected.npz"), **exp)
     json.dump(summary, open(os.path.join(HERE, "config1_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
+    survey_probe_fixture()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,155 @@
+"""Device-side dual-evaluation soak of the emission kernel.
+
+Every cell of every batch is evaluated twice ON THE DEVICE and the bits compared there (ed_batch_verify_emissions):
+  (1) k_emit_batch as shipped -- per-sample hoisted constants, per-sample tables, route binning through LDS, issued by
+      ed_batch_run together with the overlapped Viterbi / trace-back / call kernels on the side streams;
+  (2) k_emit_verify -- the reference's own per-cell loop (src/CNV_estimate.cpp:71-81: six log-Betas per cell through
+      edsf::lnbeta, nothing hoisted, tabulated or binned).
+No host round trip, no CPU checker: ~4e9 cells/s, so 1e12 cells take minutes.  The sweep concentrates on the regime of
+the one unexplained fuzz event of round 1 (shape parameters a1, a2 < 10: phi 0.05-0.5; depth 1-10; S in {1, 3, 17, 70};
+batches created and destroyed between runs as the fuzzer does) and also covers ordinary exome depths.
+
+    python tools/soak_emission.py [--seconds 120] [--variant coldinline] [--seed 1] [--out gpurun_out/soak.json]
+    AMD_SERIALIZE_KERNEL=3 python tools/soak_emission.py ...        # every kernel serialised by the runtime
+
+--variant coldinline loads exomedepth_amd/libedcore_coldinline.so (the cold special-function paths -- Gamma* below 10,
+log Gamma below 1/2 and in the Pade windows, the error path -- inlined instead of called: different code generation,
+same arithmetic).  On a mismatch the cells are printed, the case is saved under gpurun_out/ and the same inputs are run
+again through a fresh batch (transient or repeatable?).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _design(E, C, rng):
+    import numpy as np
+    cuts = np.sort(rng.choice(np.arange(1, E), size=C - 1, replace=False)) if C > 1 and E > C else np.array([], dtype=np.int64)
+    chrom_off = np.concatenate([[0], cuts, [E]]).astype(np.int32)
+    gaps = rng.integers(50, 20000, size=E)
+    start = np.cumsum(gaps).astype(np.int32)
+    end = (start + rng.integers(50, 500, size=E)).astype(np.int32)
+    return chrom_off, start, end
+
+
+def soak(seconds=60.0, seed=1, regimes=("small", "tiny", "exome"), log=print, target_cells=None, max_batch_cells=6.0e7):
+    """Run the sweep for `seconds` (or until target_cells); returns a summary dict.  Needs torch + a GPU."""
+    import numpy as np
+    import torch
+    torch.cuda.init()
+    import exomedepth_amd as ed
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    t0 = time.time()
+    stats = {r: {"batches": 0, "runs": 0, "cells": 0, "values": 0, "mismatch": 0} for r in regimes}
+    events = []
+    it = 0
+    while time.time() - t0 < seconds and (target_cells is None or sum(v["cells"] for v in stats.values()) < target_cells):
+        regime = regimes[it % len(regimes)]
+        it += 1
+        slice_end = time.time() + (1.0 if regime == "tiny" else 4.0)   # time slice of this regime
+        while time.time() < slice_end:
+            if regime == "tiny":       # the fuzzer's shapes: few samples, few exons, a batch per case
+                S = int(rng.choice([1, 3, 17, 70]))
+                E = int(rng.integers(1, 700) * rng.choice([1, 4]))
+                runs = 1
+            else:
+                S = int(rng.choice([64, 448, 512, 513, 576, 1000, 1024, 2048]))
+                E = int(min(max_batch_cells / S, rng.integers(2000, 120000)))
+                runs = 6
+            C = int(rng.integers(1, 6))
+            chrom_off, start, end = _design(E, min(C, E), rng)
+            plan = ed.Plan(chrom_off, start, end, float(rng.choice([1e-4, 1e-2])), float(rng.choice([5e4, 2e3])))
+            batch = ed.Batch(plan, S)
+            # counts: exon depth x per-sample factors, Poisson; a fifth of the cells without reads
+            depth = float(rng.uniform(1.0, 10.0)) if regime != "exome" else float(rng.choice([40.0, 100.0, 300.0]))
+            lam_e = depth * torch.exp(0.8 * torch.randn(E, 1, device=dev, dtype=torch.float32, generator=gen))
+            f_t = torch.empty(1, S, device=dev, dtype=torch.float32).uniform_(0.05, 1.0, generator=gen)
+            f_r = torch.empty(1, S, device=dev, dtype=torch.float32).uniform_(0.3, 6.0, generator=gen)
+            test = torch.poisson(lam_e * f_t, generator=gen)
+            ref = torch.poisson(lam_e * f_r, generator=gen)
+            if rng.random() < 0.7:
+                dead = torch.rand(E, S, device=dev, generator=gen) < 0.2
+                test[dead] = 0
+                ref[dead] = 0
+            test = test.to(torch.int32).contiguous()
+            ref = ref.to(torch.int32).contiguous()
+            for _ in range(runs):
+                if regime == "exome":
+                    phi = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.001, 0.02, generator=gen)
+                    p = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.03, 0.3, generator=gen)
+                else:
+                    phi = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.05, 0.5, generator=gen)
+                    p = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.02, 0.6, generator=gen)
+                mixture = float(rng.choice([1.0, 1.0, 1.0, 0.4]))
+                batch.run(test, ref, phi, p, mixture=mixture)
+                ncmp, nbad, first = batch.verify_emissions(test, ref, phi, p, mixture=mixture, cap=16)
+                st = stats[regime]
+                st["runs"] += 1; st["cells"] += E * S; st["values"] += ncmp; st["mismatch"] += nbad
+                assert ncmp == 3 * E * S, (ncmp, E, S)
+                if nbad:
+                    log("MISMATCH regime=%s E=%d S=%d C=%d: %d values" % (regime, E, S, C, nbad))
+                    for m in first:
+                        log("   exon %d sample %d state %d obs %d tot %d phi %r p %r got %r want %r" % (
+                            m["exon"], m["sample"], m["state"], m["observed"], m["total"], float(phi[m["sample"]]),
+                            float(p[m["sample"]]), m["got"], m["want"]))
+                    # the same inputs through a fresh batch, twice: transient or repeatable?
+                    again = []
+                    for _k in range(2):
+                        b2 = ed.Batch(plan, S)
+                        b2.run(test, ref, phi, p, mixture=mixture)
+                        again.append(b2.verify_emissions(test, ref, phi, p, mixture=mixture, cap=4)[1])
+                        b2.close()
+                    again.append(batch.verify_emissions(test, ref, phi, p, mixture=mixture, cap=4)[1])   # matrix as it stands
+                    log("   re-runs through fresh batches: %d, %d mismatching values; re-verify of the first matrix: %d" % tuple(again))
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    fn = os.path.join(ROOT, "gpurun_out", "soak_case_%d_%d.npz" % (seed, len(events)))
+                    np.savez_compressed(fn, chrom_off=chrom_off, start=start, end=end, test=test.cpu().numpy(), ref=ref.cpu().numpy(),
+                                        phi=phi.cpu().numpy(), p=p.cpu().numpy(), mixture=mixture, loglik=batch.loglik())
+                    events.append({"regime": regime, "E": E, "S": S, "C": C, "values": int(nbad), "first": first, "again": again,
+                                   "case": os.path.basename(fn)})
+            stats[regime]["batches"] += 1
+            batch.close(); plan.close()
+    total = {k: sum(v[k] for v in stats.values()) for k in ("batches", "runs", "cells", "values", "mismatch")}
+    return {"seconds": time.time() - t0, "seed": seed, "per_regime": stats, "total": total, "events": events,
+            "serialize_kernel": os.environ.get("AMD_SERIALIZE_KERNEL", ""), "library": os.path.basename(ed.LIB_PATH)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--variant", default="")
+    ap.add_argument("--target-cells", type=float, default=None)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    if a.variant:
+        from exomedepth_amd import _build, _lib
+        path = _build.variant_path(a.variant)
+        if not os.path.exists(path):
+            _build.build_variant(a.variant)
+        _lib.LIB_PATH = path
+        import exomedepth_amd
+        exomedepth_amd.LIB_PATH = path
+    res = soak(a.seconds, a.seed, target_cells=a.target_cells)
+    res["variant"] = a.variant or "default"
+    line = json.dumps(res)
+    print(line)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
+    sys.exit(1 if res["total"]["mismatch"] else 0)
+
+
+if __name__ == "__main__":
+    main()
