@@ -292,6 +292,69 @@ __device__ EDSF_COLD double lnbeta_cold(double x, double y, int* flag)
   return (lgx + lgy) - lgxy;
 }
 
+// Which gsl_error() calls the reference makes while it evaluates gsl_sf_lnbeta(x, y) -- the text it prints through
+// Rprintf (src/error.c:45-48) is a function of these.  Bits of the result:
+//   0-2, 3-5, 6-8  the error raised inside gsl_sf_lngamma_sgn_e for x, y, x+y (general route, src/beta.c:104-106):
+//                  0 none, 1 VP_gamma.c:1283 (EROUND: NaN or |x| too large), 2 :1239 (x == 0), 3 :1253 (sin(pi x) == 0),
+//                  4 :803 (exactly a negative integer inside lngamma_sgn_sing), 5 :1261 (x < INT_MIN + 2)
+//   9   beta.c:56 (x == 0 or y == 0)     10  beta.c:59 (a negative integer argument)     11  beta.c:44 (B(x,y) < 0)
+// Any bit set => the natural-prototype wrapper adds beta.c:163 (src/eval.h:3-9).  Zero: no error.
+// Sign and branch selection follow src/VP_gamma.c:1219-1285 and :795-894 (the sign of lngamma_sgn_sing).
+enum : unsigned { kSiteB56 = 1u << 9, kSiteB59 = 1u << 10, kSiteB44 = 1u << 11 };
+
+// sin(t) for any finite t with |t| < 2^52 (absolute error ~2e-16): t = k pi + r with a three-part pi, then the
+// polynomial of ed_psin_0pi on |r| <= pi/2.  Only signs and the |s| < 0.015 pi test of the cold path depend on it.
+__device__ __forceinline__ double psin_any(double t)
+{
+  const double k = __builtin_rint(t * 0.31830988618379067154);
+  double r = __builtin_fma(-k, 0x1.921fb54442d18p+1, t);
+  r = __builtin_fma(-k, 0x1.1a62633145c07p-53, r);
+  r = __builtin_fma(-k, -0x1.f1976b7ed8fbcp-109, r);
+  const double a = ed_psin_0pi(fabs(r));
+  const bool odd = (((long long)k) & 1ll) != 0;
+  return ((r < 0.0) != odd) ? -a : a;
+}
+
+__device__ __forceinline__ unsigned lngamma_site(double x, double* sgn)
+{
+  if (fabs(x - 1.0) < 0.01 || fabs(x - 2.0) < 0.01 || x >= 0.5) { *sgn = 1.0; return 0u; }
+  if (x == 0.0) { *sgn = 0.0; return 2u; }
+  if (fabs(x) < 0.02) { *sgn = (x >= 0.0) ? 1.0 : -1.0; return 0u; }
+  if (x > -0.5 / (EDSF_DBL_EPS * EDSF_M_PI)) {
+    const double s = psin_any(EDSF_M_PI * x);
+    if (s == 0.0) { *sgn = 0.0; return 3u; }
+    if (fabs(s) < EDSF_M_PI * 0.015) {
+      if (x < -2147483648.0 + 2.0) { *sgn = 0.0; return 5u; }
+      const int N = -(int)(x - 0.5);
+      const double eps = x + N;
+      if (eps == 0.0) { *sgn = 0.0; return 4u; }
+      if (N == 1) *sgn = (eps > 0.0) ? -1.0 : 1.0;
+      else *sgn = ((N & 1) ? -1.0 : 1.0) * ((eps > 0.0) ? 1.0 : -1.0);
+      return 0u;
+    }
+    *sgn = (s > 0.0) ? 1.0 : -1.0;
+    return 0u;
+  }
+  *sgn = 0.0;
+  return 1u;
+}
+
+__device__ __noinline__ unsigned lnbeta_sites(double x, double y)
+{
+  if (x == 0.0 || y == 0.0) return kSiteB56;
+  if ((x < 0.0 && x == __builtin_floor(x)) || (y < 0.0 && y == __builtin_floor(y))) return kSiteB59;
+  if (x > 0.0 && y > 0.0) {
+    const double mx = (x > y ? x : y), mn = (x < y ? x : y);
+    if (mn / mx < 0.2) return 0u;
+  }
+  double sx, sy, sxy;
+  unsigned code = lngamma_site(x, &sx);
+  code |= lngamma_site(y, &sy) << 3;
+  code |= lngamma_site(x + y, &sxy) << 6;
+  if (sx * sy * sxy == -1.0) code |= kSiteB44;
+  return code;
+}
+
 // The two value-exact evaluation routes of log B for x,y > 0 (src/beta.c:62-113), split so that a
 // kernel can bin its tasks by route and run each route in branch-uniform waves:
 //   ratio route   min/max < 0.2 : Gamma* form (:69-97).  Only symmetric expressions of (x,y) occur

@@ -354,6 +354,28 @@ k_emit_rows(const double* __restrict__ phi, const double* __restrict__ expected,
   if (nflag) atomicAdd(nerr, (unsigned long long)nflag);
 }
 
+// Error sites of the six gsl_sf_lnbeta calls of every row, in the reference's call order (edsf::lnbeta_sites):
+// codes[6 i + 2 st + 0] for lnbeta(a1 + obs, a2 + tot - obs), [.. + 1] for lnbeta(a1, a2)  (src/CNV_estimate.cpp:49)
+__global__ void __launch_bounds__(kEmitBlock)
+k_emit_rows_sites(const double* __restrict__ phi, const double* __restrict__ expected, const int32_t* __restrict__ total,
+                  const int32_t* __restrict__ observed, int64_t n, double mixture, uint16_t* __restrict__ codes)
+{
+  const int64_t i = (int64_t)blockIdx.x * kEmitBlock + threadIdx.x;
+  if (i >= n) return;
+  const double e = expected[i];
+  const double sd = __builtin_sqrt((phi[i] * e) * (1. - e));
+  double ep[3];
+  state_props(e, mixture, ep);
+  const int32_t tot = total[i], obs = observed[i];
+#pragma unroll 1
+  for (int st = 0; st < 3; ++st) {
+    double a1, a2;
+    shape_params(ep[st], sd, a1, a2);
+    codes[i * 6 + st * 2 + 0] = (uint16_t)edsf::lnbeta_sites(a1 + (double)obs, (a2 + (double)tot) - (double)obs);
+    codes[i * 6 + st * 2 + 1] = (uint16_t)edsf::lnbeta_sites(a1, a2);
+  }
+}
+
 // Self-check of the batched emissions (ed_batch_verify_emissions): every cell is evaluated a second time with the
 // straight per-cell arithmetic of the reference's loop -- six log-Betas per cell as src/CNV_estimate.cpp:71-81 has
 // them, shape parameters recomputed from (phi, expected), no hoisted constants, no tables, no binning, no LDS -- and
@@ -1568,6 +1590,63 @@ ED_EXPORT int ed_get_loglike_matrix(const double* phi, const double* expected, c
   unsigned long long ne = 0;
   HIP_TRY(hipMemcpy(&ne, dnerr.p, 8, hipMemcpyDeviceToHost));
   if (n_gsl_errors) *n_gsl_errors = (int64_t)ne;
+  return ED_OK;
+}
+
+// The text the reference prints while it computes the same matrix: one gsl_error() call = two Rprintf lines
+// (src/error.c:45-48), in the order the reference makes them (rows in order; deletion, normal, duplication;
+// within myprob the left operand of the subtraction first).  The sites are classified on the device
+// (k_emit_rows_sites); only the formatting is host code.
+ED_EXPORT int ed_get_loglike_matrix_messages(const double* phi, const double* expected, const int32_t* total,
+                                             const int32_t* observed, int64_t n, double mixture, char* buf, size_t cap,
+                                             size_t* needed)
+{
+  if (n < 0 || !needed || (n > 0 && (!phi || !expected || !total || !observed)) || (cap > 0 && !buf))
+    return ed_fail(ED_ERR_INVALID, "ed_get_loglike_matrix_messages: bad arguments");
+  if (int rc = require_device()) return rc;
+  *needed = 0;
+  if (cap > 0) buf[0] = 0;
+  if (n == 0) return ED_OK;
+  DevBuf dphi, dexp, dtot, dobs, dcodes;
+  HIP_TRY(dphi.alloc(n * 8)); HIP_TRY(dexp.alloc(n * 8)); HIP_TRY(dtot.alloc(n * 4)); HIP_TRY(dobs.alloc(n * 4));
+  HIP_TRY(dcodes.alloc((size_t)n * 12));
+  HIP_TRY(hipMemcpy(dphi.p, phi, n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dexp.p, expected, n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dtot.p, total, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dobs.p, observed, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_emit_rows_sites, dim3((unsigned)((n + kEmitBlock - 1) / kEmitBlock)), dim3(kEmitBlock), 0, 0,
+                     dphi.as<double>(), dexp.as<double>(), dtot.as<int32_t>(), dobs.as<int32_t>(), n, mixture,
+                     dcodes.as<uint16_t>());
+  HIP_TRY(hipGetLastError());
+  std::vector<uint16_t> codes((size_t)n * 6);
+  HIP_TRY(hipMemcpy(codes.data(), dcodes.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  size_t len = 0;
+  auto emit = [&](const char* file, int line, const char* reason) {
+    char tmp[160];
+    const int k = snprintf(tmp, sizeof tmp, "ERROR %s %i %s\nDefault GSL error handler invoked.\n", file, line, reason);
+    if (k <= 0) return;
+    for (int j = 0; j < k; ++j)
+      if (len + (size_t)j + 1 < cap) buf[len + j] = tmp[j];
+    len += (size_t)k;
+  };
+  static const int kGammaLine[6] = {0, 1283, 1239, 1253, 803, 1261};          // src/VP_gamma.c
+  static const char* const kGammaWhat[6] = {"", "error", "domain error", "domain error", "error", "error"};
+  for (size_t c = 0; c < codes.size(); ++c) {
+    const unsigned code = codes[c];
+    if (!code) continue;
+    if (code & (1u << 9)) emit("beta.c", 56, "domain error");
+    else if (code & (1u << 10)) emit("beta.c", 59, "domain error");
+    else {
+      for (int t = 0; t < 3; ++t) {
+        const unsigned g = (code >> (3 * t)) & 7u;
+        if (g >= 1 && g <= 5) emit("VP_gamma.c", kGammaLine[g], kGammaWhat[g]);
+      }
+      if (code & (1u << 11)) emit("beta.c", 44, "domain error");
+    }
+    emit("beta.c", 163, "gsl_sf_lnbeta_e(x, y, &result)");                     // src/eval.h:3-9 via src/beta.c:161-164
+  }
+  if (cap > 0) buf[std::min(len, cap - 1)] = 0;
+  *needed = len;
   return ED_OK;
 }
 

@@ -59,6 +59,15 @@ int ed_device_info(int device, char* name, size_t name_len, int* compute_units, 
 int ed_get_loglike_matrix(const double* phi, const double* expected, const int32_t* total, const int32_t* observed,
                           int64_t n, double mixture, double* out, int64_t* n_gsl_errors);
 
+/* What the reference PRINTS while it computes that matrix for rows outside the model's domain: every gsl_error() call
+ * is two Rprintf lines, "ERROR <file> <line> <reason>\n" and "Default GSL error handler invoked.\n" (src/error.c:45-48;
+ * the sites are src/beta.c:44, :56, :59, :163 and src/VP_gamma.c:803, :1239, :1253, :1261, :1283), in the reference's
+ * order.  The events happen on the device, so the library hands the text back and the R shim prints it.
+ * buf[cap] receives at most cap - 1 characters + NUL; *needed = length of the whole text (call with cap = 0 to size it).
+ * Same arguments as ed_get_loglike_matrix. */
+int ed_get_loglike_matrix_messages(const double* phi, const double* expected, const int32_t* total, const int32_t* observed,
+                                   int64_t n, double mixture, char* buf, size_t cap, size_t* needed);
+
 /* C_hmm: reference src/hmm.cpp:18-167.
  *   nstates must be 3 (else ED_ERR_INVALID; the reference prints and returns a C NULL, :37-40)
  *   transitions[9]        3x3 column-major (:25)

@@ -1,0 +1,120 @@
+/* TEST INFRASTRUCTURE -- a miniature runtime behind the declarations of Rinternals.h / R_ext/Rdynload.h, just enough
+ * to load shim/edcore_shim.c without R and drive its .Call entries from tests/test_shim.py:
+ * vectors are malloc'ed blocks, Rprintf appends to a capture buffer, Rf_error longjmps back to minir_call5/6, and
+ * R_registerRoutines / R_useDynamicSymbols record what the shim registers.  Nothing here is R's implementation. */
+#include <setjmp.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "Rinternals.h"
+#include "R_ext/Rdynload.h"
+
+struct SEXPREC { SEXPTYPE type; R_xlen_t n; int nrow, ncol; void *data; };
+static struct SEXPREC nil_rec = {0, 0, 0, 0, NULL};
+SEXP R_NilValue = &nil_rec;
+
+static char g_out[1 << 20];
+static size_t g_out_len = 0;
+static char g_err[4096];
+static int g_protect = 0, g_protect_max = 0;
+static jmp_buf g_jmp;
+static int g_jmp_armed = 0;
+static char g_reg_names[8][64];
+static int g_reg_nargs[8], g_reg_n = -1, g_dyn = -1;
+static DL_FUNC g_reg_fun[8];
+
+double *REAL(SEXP x) { return (double *)x->data; }
+int *INTEGER(SEXP x) { return (int *)x->data; }
+R_xlen_t XLENGTH(SEXP x) { return x->n; }
+int LENGTH(SEXP x) { return (int)x->n; }
+SEXP Rf_allocVector(SEXPTYPE type, R_xlen_t length)
+{
+  SEXP s = (SEXP)calloc(1, sizeof *s);
+  const size_t el = type == REALSXP ? 8 : (type == INTSXP ? 4 : sizeof(SEXP));
+  s->type = type; s->n = length; s->nrow = (int)length; s->ncol = 1;
+  s->data = calloc((size_t)(length > 0 ? length : 1), el);
+  return s;
+}
+SEXP Rf_allocMatrix(SEXPTYPE type, int nrow, int ncol)
+{
+  SEXP s = Rf_allocVector(type, (R_xlen_t)nrow * ncol);
+  s->nrow = nrow; s->ncol = ncol;
+  return s;
+}
+SEXP Rf_protect(SEXP x) { if (++g_protect > g_protect_max) g_protect_max = g_protect; return x; }
+void Rf_unprotect(int n) { g_protect -= n; }
+SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP *)x->data)[i] = v; return v; }
+SEXP VECTOR_ELT(SEXP x, R_xlen_t i) { return ((SEXP *)x->data)[i]; }
+void Rprintf(const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  const int k = vsnprintf(g_out + g_out_len, sizeof g_out - g_out_len, fmt, ap);
+  va_end(ap);
+  if (k > 0) g_out_len += (size_t)k < sizeof g_out - g_out_len ? (size_t)k : sizeof g_out - g_out_len - 1;
+}
+void Rf_error(const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  if (g_jmp_armed) longjmp(g_jmp, 1);
+  fprintf(stderr, "mini_r: Rf_error outside a call: %s\n", g_err);
+  abort();
+}
+char *R_alloc(size_t n, int size) { return (char *)calloc(n ? n : 1, (size_t)size); }   /* (leaks: a test process) */
+
+int R_registerRoutines(DllInfo *info, const R_CMethodDef *const c, const R_CallMethodDef *const call,
+                       const R_FortranMethodDef *const f, const R_ExternalMethodDef *const e)
+{
+  (void)info;
+  g_reg_n = 0;
+  if (c || f || e) g_reg_n = -100;                       /* the reference registers .Call routines only */
+  for (int i = 0; call && call[i].name && i < 8; i++) {
+    strncpy(g_reg_names[i], call[i].name, 63);
+    g_reg_nargs[i] = call[i].numArgs;
+    g_reg_fun[i] = call[i].fun;
+    g_reg_n = i + 1;
+  }
+  return 1;
+}
+Rboolean R_useDynamicSymbols(DllInfo *info, Rboolean value) { (void)info; g_dyn = (int)value; return TRUE; }
+
+/* ---- what the test drives ---- */
+int minir_n_registered(void) { return g_reg_n; }
+const char *minir_registered_name(int i) { return g_reg_names[i]; }
+int minir_registered_nargs(int i) { return g_reg_nargs[i]; }
+void *minir_registered_fun(int i) { return (void *)g_reg_fun[i]; }
+int minir_dynamic_symbols(void) { return g_dyn; }
+const char *minir_output(void) { g_out[g_out_len] = 0; return g_out; }
+void minir_reset_output(void) { g_out_len = 0; g_out[0] = 0; g_err[0] = 0; }
+const char *minir_error(void) { return g_err; }
+int minir_protect_balance(void) { return g_protect; }
+int minir_protect_max(void) { return g_protect_max; }
+SEXP minir_real(const double *v, R_xlen_t n) { SEXP s = Rf_allocVector(REALSXP, n); if (n) memcpy(s->data, v, (size_t)n * 8); return s; }
+SEXP minir_int(const int *v, R_xlen_t n) { SEXP s = Rf_allocVector(INTSXP, n); if (n) memcpy(s->data, v, (size_t)n * 4); return s; }
+int minir_type(SEXP s) { return (int)s->type; }
+int minir_nrow(SEXP s) { return s->nrow; }
+int minir_ncol(SEXP s) { return s->ncol; }
+/* .Call through the registered pointer; returns NULL (and keeps the message) if the routine raised an R error */
+SEXP minir_call5(void *fn, SEXP a, SEXP b, SEXP c, SEXP d, SEXP e)
+{
+  SEXP r = NULL;
+  g_protect = 0;
+  g_jmp_armed = 1;
+  if (setjmp(g_jmp) == 0) r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP))fn)(a, b, c, d, e);
+  g_jmp_armed = 0;
+  return r;
+}
+SEXP minir_call6(void *fn, SEXP a, SEXP b, SEXP c, SEXP d, SEXP e, SEXP f)
+{
+  SEXP r = NULL;
+  g_protect = 0;
+  g_jmp_armed = 1;
+  if (setjmp(g_jmp) == 0) r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP))fn)(a, b, c, d, e, f);
+  g_jmp_armed = 0;
+  return r;
+}

@@ -1,0 +1,193 @@
+"""The R side of the drop-in, as source: shim/edcore_shim.c compiled against declarations-only R headers (tests/rapi/)
+and driven through a miniature runtime (tests/rapi/mini_r.c) -- R itself is not in the image.
+
+CPU part (no GPU): the shim compiles warning-free and links against libedcore.so; R_init_ExomeDepth registers exactly
+what reference src/ExomeDepth_init.c:14-24 registers; the texts it prints / raises are the reference's
+(src/CNV_estimate.cpp:61, src/hmm.cpp:38); without a device the .Call raises an R error (no CPU fallback).
+GPU part: the two .Call entries through SEXPs give, bit for bit, what the ctypes path gives; the GSL error lines
+(src/error.c:45-48) come out as the reference prints them.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAPI = os.path.join(ROOT, "tests", "rapi")
+OUT = os.path.join(RAPI, "_build")
+
+# typed in from the reference (src/CNV_estimate.cpp:61, src/hmm.cpp:38, src/error.c:45-48)
+MIXTURE_FMT = "As a warning (this could be normal), the mixture coefficient is %f\n"
+NSTATES_MSG = "ERROR: The code must assume 3 states"
+HANDLER_LINE = "Default GSL error handler invoked.\n"
+
+
+@pytest.fixture(scope="module")
+def shim():
+    from exomedepth_amd import _build
+    if not os.path.exists(_build.LIB):
+        _build.build()
+    os.makedirs(OUT, exist_ok=True)
+    minir = os.path.join(OUT, "libminir.so")
+    so = os.path.join(OUT, "edcore_shim.so")
+    libdir = os.path.dirname(_build.LIB)
+    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-I", RAPI, os.path.join(RAPI, "mini_r.c"),
+                    "-o", minir], check=True)
+    # the shim exactly as an R package would build it (shim/Makevars), with tests/rapi standing where R's include dir is
+    subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type", "-std=gnu99", "-shared", "-fPIC", "-I", RAPI,
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "shim", "edcore_shim.c"), "-o", so,
+                    "-L", libdir, "-ledcore", "-Wl,-rpath," + libdir], check=True)
+    try:   # when torch shares the process its HIP runtime must come up first (see tests/conftest.py::edlib)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    R = C.CDLL(minir, mode=C.RTLD_GLOBAL)
+    S = C.CDLL(so)
+    vp = C.c_void_p
+    for name, res, args in (("minir_n_registered", C.c_int, []), ("minir_registered_name", C.c_char_p, [C.c_int]),
+                            ("minir_registered_nargs", C.c_int, [C.c_int]), ("minir_registered_fun", vp, [C.c_int]),
+                            ("minir_dynamic_symbols", C.c_int, []), ("minir_output", C.c_char_p, []),
+                            ("minir_reset_output", None, []), ("minir_error", C.c_char_p, []),
+                            ("minir_protect_balance", C.c_int, []), ("minir_protect_max", C.c_int, []),
+                            ("minir_real", vp, [vp, C.c_ssize_t]), ("minir_int", vp, [vp, C.c_ssize_t]),
+                            ("minir_type", C.c_int, [vp]), ("minir_nrow", C.c_int, [vp]), ("minir_ncol", C.c_int, [vp]),
+                            ("minir_call5", vp, [vp] * 6), ("minir_call6", vp, [vp] * 7),
+                            ("REAL", C.POINTER(C.c_double), [vp]), ("XLENGTH", C.c_ssize_t, [vp]), ("VECTOR_ELT", vp, [vp, C.c_ssize_t])):
+        fn = getattr(R, name)
+        fn.restype, fn.argtypes = res, args
+    S.R_init_ExomeDepth.argtypes = [vp]
+    S.R_init_ExomeDepth.restype = None
+    S.R_init_ExomeDepth(None)
+    entries = {R.minir_registered_name(i).decode(): (R.minir_registered_nargs(i), R.minir_registered_fun(i))
+               for i in range(max(R.minir_n_registered(), 0))}
+
+    class Shim:
+        pass
+    sh = Shim()
+    sh.R, sh.S, sh.entries = R, S, entries
+
+    def real(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return R.minir_real(a.ctypes.data, a.size)
+
+    def integer(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        return R.minir_int(a.ctypes.data, a.size)
+
+    def values(sexp):
+        n = R.XLENGTH(sexp)
+        return np.ctypeslib.as_array(R.REAL(sexp), shape=(n,)).copy() if n else np.zeros(0)
+
+    def dot_call(name, *args):          # .Call(name, ...): by registered name, arity checked as R checks it
+        nargs, fn = entries[name]
+        assert len(args) == nargs
+        R.minir_reset_output()
+        r = (R.minir_call5 if nargs == 5 else R.minir_call6)(fn, *args)
+        return r, R.minir_output().decode(), R.minir_error().decode()
+    sh.real, sh.integer, sh.values, sh.dot_call = real, integer, values, dot_call
+    return sh
+
+
+def test_registration_is_the_references(shim):
+    """reference src/ExomeDepth_init.c:14-24: {"C_hmm", 6}, {"get_loglike_matrix", 5}, nothing else, dynamic symbols off."""
+    assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5}
+    assert shim.R.minir_n_registered() == 2
+    assert shim.R.minir_dynamic_symbols() == 0
+    for name, (_, fn) in shim.entries.items():
+        assert fn == C.cast(getattr(shim.S, name), C.c_void_p).value     # the registered pointers are the exported entries
+
+
+def test_shim_texts_are_the_references(shim):
+    src = open(os.path.join(ROOT, "shim", "edcore_shim.c")).read()
+    assert '"' + MIXTURE_FMT.replace("\n", "\\n") + '"' in src
+    assert '"' + NSTATES_MSG + '"' in src
+
+
+def test_mixture_notice_and_no_cpu_fallback(shim):
+    n = 4
+    r, out, err = shim.dot_call("get_loglike_matrix", shim.real(np.full(n, 0.01)), shim.real(np.full(n, 0.2)),
+                                shim.integer([100, 50, 0, 10]), shim.integer([20, 5, 0, 3]), shim.real([0.5]))
+    assert out.startswith(MIXTURE_FMT % 0.5)
+    from exomedepth_amd import _lib
+    if _lib.lib().ed_device_count() == 0:
+        assert r is None and "no usable HIP device" in err          # an R error, not a silently computed matrix
+    else:
+        assert r is not None and err == "" and (shim.R.minir_nrow(r), shim.R.minir_ncol(r)) == (n, 3)
+    assert shim.R.minir_protect_balance() == 0 or r is None
+
+
+def test_nstates_other_than_three_raises(shim):
+    r, out, err = shim.dot_call("C_hmm", shim.integer([2]), shim.integer([5]), shim.real(np.full(4, 0.5)), shim.real(np.zeros(10)),
+                                shim.integer(np.arange(5)), shim.real([1.0]))
+    assert r is None and err == NSTATES_MSG
+
+
+@pytest.mark.gpu
+def test_get_loglike_matrix_through_sexp_equals_ctypes_path(shim, edlib):
+    rng = np.random.default_rng(5)
+    n = 5000
+    phi = rng.uniform(0.001, 0.3, n); e = rng.uniform(0.02, 0.9, n)
+    tot = rng.integers(0, 3000, n).astype(np.int32); obs = (tot * rng.uniform(0, 1, n)).astype(np.int32)
+    for mix in (1.0, 0.4):
+        r, out, err = shim.dot_call("get_loglike_matrix", shim.real(phi), shim.real(e), shim.integer(tot), shim.integer(obs),
+                                    shim.real([mix]))
+        assert r is not None and err == ""
+        assert out == ("" if mix == 1.0 else MIXTURE_FMT % mix)
+        assert (shim.R.minir_type(r), shim.R.minir_nrow(r), shim.R.minir_ncol(r)) == (14, n, 3)     # REALSXP n x 3
+        got = shim.values(r).reshape(3, n).T                                                        # column-major
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            want = edlib.get_loglike_matrix(phi, e, tot, obs, mixture=mix)
+        assert np.array_equal(np.ascontiguousarray(got).view(np.int64), np.ascontiguousarray(want).view(np.int64))
+        assert shim.R.minir_protect_balance() == 0
+
+
+@pytest.mark.gpu
+def test_c_hmm_through_sexp_equals_ctypes_path(shim, edlib):
+    T = np.full((3, 3), 1 / 3)
+    ll = np.array([[0, -10, -10]] * 3 + [[-10, -10, 0]] * 3 + [[-10, 0, -10]] * 4, dtype=float)   # reference R/tools.R:74-79
+    pos = np.arange(1, 11)
+    cases = [(T, ll, pos, 1.0)]
+    rng = np.random.default_rng(9)
+    t = 1e-3
+    for n in (2, 57, 4000):
+        cases.append((np.array([[1 - t, t / 2, t / 2], [.5, .5, 0], [.5, 0, .5]]), rng.normal(-3, 3, (n, 3)),
+                      np.cumsum(rng.integers(1, 30000, n)), 50000.0))
+    for Tm, llm, p, L in cases:
+        n = llm.shape[0]
+        r, out, err = shim.dot_call("C_hmm", shim.integer([3]), shim.integer([n]), shim.real(Tm.T.ravel()), shim.real(llm.T.ravel()),
+                                    shim.integer(p), shim.real([L]))
+        assert r is not None and err == "" and out == ""
+        assert shim.R.minir_type(r) == 19 and shim.R.XLENGTH(r) == 2                              # VECSXP of 2 (src/hmm.cpp:133)
+        path, calls = shim.R.VECTOR_ELT(r, 0), shim.R.VECTOR_ELT(r, 1)
+        want = edlib.viterbi_hmm(Tm, llm, p, L)
+        assert shim.R.minir_type(path) == 14 and np.array_equal(shim.values(path), want["Viterbi.path"].astype(float))
+        k = len(want["calls"])
+        assert (shim.R.minir_type(calls), shim.R.minir_nrow(calls), shim.R.minir_ncol(calls)) == (14, k, 4)
+        got = shim.values(calls).reshape(4, k)
+        for j, name in enumerate(("start.p", "end.p", "type", "nexons")):
+            assert np.array_equal(got[j], want["calls"][name])
+        assert shim.R.minir_protect_balance() == 0
+    path, calls = shim.R.VECTOR_ELT(shim.dot_call("C_hmm", shim.integer([3]), shim.integer([10]), shim.real(T.T.ravel()),
+                                                  shim.real(ll.T.ravel()), shim.integer(pos), shim.real([1.0]))[0], 0), None
+    assert shim.values(path).tolist() == [0, 0, 0, 2, 2, 2, 1, 1, 1, 0]
+
+
+@pytest.mark.gpu
+def test_gsl_error_lines_are_printed_as_the_reference_prints_them(shim, edlib):
+    """expected = 0 makes every shape parameter NaN: each of the row's six gsl_sf_lnbeta calls fails three times in
+    gsl_sf_lngamma_sgn_e (src/VP_gamma.c:1283, GSL_EROUND) and once in the natural-prototype wrapper (src/beta.c:163),
+    two lines per gsl_error call (src/error.c:45-48); the values are 0.0.  total = observed = 0 with a zero
+    shape parameter hits the x == 0 domain error of src/beta.c:56."""
+    phi = np.array([0.01, 0.01, 0.01]); e = np.array([0.2, 0.0, 0.2])
+    tot = np.array([100, 10, 7], np.int32); obs = np.array([20, 3, 1], np.int32)
+    r, out, err = shim.dot_call("get_loglike_matrix", shim.real(phi), shim.real(e), shim.integer(tot), shim.integer(obs), shim.real([1.0]))
+    assert r is not None and err == ""
+    got = shim.values(r).reshape(3, 3).T
+    assert np.all(got[1] == 0.0) and np.all(np.isfinite(got))
+    one_call = ("ERROR VP_gamma.c 1283 error\n" + HANDLER_LINE) * 3 + "ERROR beta.c 163 gsl_sf_lnbeta_e(x, y, &result)\n" + HANDLER_LINE
+    assert out == one_call * 6
