@@ -438,6 +438,7 @@ class ExomeDepth:
         if test.size != reference.size:
             raise ValueError("Length of test and numeric must match")   # R/class_definition.R:92
         self.test, self.reference = test, reference
+        self.prop_tumor = float(prop_tumor)
         self.phi = np.zeros(0)
         self.expected = np.zeros(0)
         self.likelihood = np.zeros((0, 3))
@@ -523,9 +524,10 @@ class ExomeDepth:
             plan = Plan(chrom_off, start, end, transition_probability, expected_CNV_length)
             batch = Batch(plan, 1)
             try:
-                # the likelihood is recomputed on the device from the same inputs (bit-identical to the slot)
+                # the likelihood is recomputed on the device from the same inputs -- prop.tumor included -- hence
+                # bit-identical to the slot the reference runs its Viterbi on (R/class_definition.R:364)
                 batch.run(_as_r_integer(self.test).reshape(n, 1), _as_r_integer(self.reference).reshape(n, 1),
-                          self.phi[:1], self.expected[:1])
+                          self.phi[:1], self.expected[:1], mixture=self.prop_tumor)
                 raw = batch.calls()
                 self.Viterbi_path = batch.path()[:, 0].astype(np.int64)
             finally:
@@ -559,12 +561,14 @@ class ExomeDepth:
             bf = float(np.sum(self.likelihood[s:e + 1, col] - self.likelihood[s:e + 1, 1]))
             reads_expected = int(np.sum(total[s:e + 1] * self.expected[s:e + 1]))
             reads_observed = float(np.sum(self.test[s:e + 1]))
+            with np.errstate(divide="ignore", invalid="ignore"):   # obs / 0 is Inf in R (and in k_call_info), 0 / 0 NaN
+                ratio = float(np.float64(reads_observed) / np.float64(reads_expected))
             cid = ("chr%s:%d-%d" % (chrom_sorted[s], start[s], end[e])).replace("chrchr", "chr")
             calls.append({"start.p": s + 1, "end.p": e + 1, "type": typ, "nexons": int(r["nexons"]),
                           "start": int(start[s]), "end": int(end[e]), "chromosome": chrom_sorted[s], "id": cid,
                           "BF": _signif(np.log10(np.e) * bf, 3), "reads.expected": reads_expected,
                           "reads.observed": reads_observed,
-                          "reads.ratio": _signif(reads_observed / reads_expected, 3) if reads_expected else float("nan")})
+                          "reads.ratio": _signif(ratio, 3)})
         self.CNV_calls = calls
         return self
 

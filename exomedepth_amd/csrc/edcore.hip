@@ -377,55 +377,68 @@ k_emit_rows_sites(const double* __restrict__ phi, const double* __restrict__ exp
 }
 
 // Self-check of the batched emissions (ed_batch_verify_emissions): every cell is evaluated a second time with the
-// straight per-cell arithmetic of the reference's loop -- six log-Betas per cell as src/CNV_estimate.cpp:71-81 has
-// them, shape parameters recomputed from (phi, expected), no hoisted constants, no tables, no binning, no LDS -- and
-// compared bit for bit with what k_emit_batch left in the likelihood matrix, on the device.  NaN matches NaN.
-// counters[0] = mismatching values, counters[1] = values compared; the first `cap` mismatches are recorded.
+// straight per-cell arithmetic of the reference's loop -- log B(a1 + obs, a2 + tot - obs) - log B(a1, a2) per state as
+// src/CNV_estimate.cpp:44-50, :71-81 has it, shape parameters recomputed from (phi, expected), through edsf::lnbeta:
+// no tables, no binning, no LDS -- and compared bit for bit with what k_emit_batch left in the likelihood matrix, on the
+// device.  A thread walks kVerifyRun consecutive exons of one sample, so log B(a1, a2) -- the same call with the same
+// arguments for every exon of the sample -- is evaluated once per thread and state.  NaN matches NaN.
+// counters[0] = mismatching values, [1] = values compared, [2] = mismatches recorded in `first` (up to cap).
+constexpr int kVerifyRun = 8;
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_verify(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ phi,
               const double* __restrict__ expected, double mixture, int64_t E, int64_t S, const double* __restrict__ loglik,
               unsigned long long* __restrict__ counters, ed_emit_mismatch* __restrict__ first, int64_t cap)
 {
   const int64_t s_raw = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int64_t e_raw = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (kEmitBlock / 64) + (threadIdx.x >> 6);
-  const bool live = s_raw < S && e_raw < E;      // idle lanes shadow cell (0, 0) and count nothing
-  const int64_t s = live ? s_raw : 0, e = live ? e_raw : 0;
+  const int64_t e0 = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (kEmitBlock / 64) + (threadIdx.x >> 6)) * kVerifyRun;
+  const bool live_s = s_raw < S;
+  const int64_t s = live_s ? s_raw : 0;      // idle lanes shadow sample 0 and count nothing
   const double ex = expected[s];
   const double sd = __builtin_sqrt((phi[s] * ex) * (1. - ex));
   double ep[3];
   state_props(ex, mixture, ep);
-  const int32_t obs = test[e * S + s];
-  const int32_t tot = obs + ref[e * S + s];
-  int bad = 0;
+  int bad = 0, ncell = 0;
 #pragma unroll 1
   for (int st = 0; st < 3; ++st) {
     double a1, a2;
     shape_params(ep[st], sd, a1, a2);
-    int f1 = 0, f2 = 0;
-    const double v1 = edsf::lnbeta(a1 + (double)obs, (a2 + (double)tot) - (double)obs, &f1);
+    int f2 = 0;
     const double v0 = edsf::lnbeta(a1, a2, &f2);
-    const double want = v1 - v0;
-    const double got = loglik[(e * 3 + st) * S + s];
-    const bool same = (__double_as_longlong(want) == __double_as_longlong(got)) || (want != want && got != got);
-    if (live && !same) {
-      ++bad;
-      const unsigned long long k = atomicAdd(&counters[2], 1ull);
-      if ((int64_t)k < cap) {
-        ed_emit_mismatch m;
-        m.exon = e; m.sample = s; m.state = st; m.observed = obs; m.total = tot;
-        m.got = got; m.want = want;
-        first[k] = m;
+#pragma unroll 1
+    for (int k = 0; k < kVerifyRun; ++k) {
+      const int64_t e = e0 + k;
+      const bool live = live_s && e < E;
+      const int64_t ec = e < E ? e : E - 1;
+      const int32_t obs = test[ec * S + s];
+      const int32_t tot = obs + ref[ec * S + s];
+      int f1 = 0;
+      const double v1 = edsf::lnbeta(a1 + (double)obs, (a2 + (double)tot) - (double)obs, &f1);
+      const double want = v1 - v0;
+      const double got = loglik[(ec * 3 + st) * S + s];
+      const bool same = (__double_as_longlong(want) == __double_as_longlong(got)) || (want != want && got != got);
+      if (live && st == 0) ++ncell;
+      if (live && !same) {
+        ++bad;
+        const unsigned long long q = atomicAdd(&counters[2], 1ull);
+        if ((int64_t)q < cap) {
+          ed_emit_mismatch m;
+          m.exon = e; m.sample = s; m.state = st; m.observed = obs; m.total = tot; m.pad_ = 0;
+          m.got = got; m.want = want;
+          first[q] = m;
+        }
       }
     }
   }
   // one pair of atomics per wave
-  const unsigned long long nlive = __popcll(__ballot(live));
-  int wsum = bad;
+  int wbad = bad, wcell = ncell;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+  for (int d = 32; d >= 1; d >>= 1) {
+    wbad += __shfl_xor(wbad, d, 64);
+    wcell += __shfl_xor(wcell, d, 64);
+  }
   if ((threadIdx.x & 63) == 0) {
-    if (wsum) atomicAdd(&counters[0], (unsigned long long)wsum);
-    if (nlive) atomicAdd(&counters[1], 3ull * nlive);
+    if (wbad) atomicAdd(&counters[0], (unsigned long long)wbad);
+    if (wcell) atomicAdd(&counters[1], 3ull * (unsigned long long)wcell);
   }
 }
 
@@ -2378,7 +2391,8 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
   DevBuf dcnt, dfirst;
   HIP_TRY(dcnt.alloc(24)); HIP_TRY(dfirst.alloc((size_t)cap * sizeof(ed_emit_mismatch)));
   HIP_TRY(hipMemsetAsync(dcnt.p, 0, 24, b->stream));
-  const int64_t eblk = (E + kEmitBlock / 64 - 1) / (kEmitBlock / 64);
+  const int64_t rows_per_block = (int64_t)(kEmitBlock / 64) * kVerifyRun;
+  const int64_t eblk = (E + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL(k_emit_verify, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535), (unsigned)((eblk + 65534) / 65535)),
                      dim3(kEmitBlock), 0, b->stream, d_test, d_ref, d_phi, d_expected, mixture, E, S, b->d_loglik,
                      dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap);

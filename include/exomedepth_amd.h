@@ -283,6 +283,11 @@ int ed_select_reference_set_part(const int32_t* d_test, const int32_t* d_refs, i
  * reference.choice (:143-145) on a complete table of raw rows.  Host code only (no device needed). */
 int ed_refset_finalize(ed_refset_row* rows, int64_t n_refs, int32_t* n_chosen);
 
+/* The bins select.reference.set keeps when n.bins.reduced > 0: 0-based positions of  x[seq(1, len, len / n_reduced)]
+ * (R/optimize_reference_set.R:86) with R's seq() and subscript-truncation semantics.  positions[cap] receives the first
+ * cap of them, *n_positions their number (at most n_reduced + 1).  Host code only (no device needed). */
+int ed_refset_thin_positions(int64_t len, int64_t n_reduced, int64_t* positions, int64_t cap, int64_t* n_positions);
+
 /* get.power.betabinom(size, my.phi, my.p, my.alt.p) (reference R/tools.R:128-166), default mode (theory = FALSE,
  * frequentist = FALSE, limit = FALSE): the expected log10 Bayes factor sum_{x=0}^{size} dbetabinom(x; alt) log10 BF(x),
  * for n parameter sets at once.  HOST arrays; synchronous. */

@@ -58,6 +58,8 @@ def lib():
         L.edo_psi_v.restype = None
         L.edo_fit_mle.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.edo_fit_mle.restype = C.c_int
+        L.edo_fit_mle_hist.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.edo_fit_mle_hist.restype = C.c_int
         L.edo_fit_mle_groups.argtypes = [_ip, _ip, _ip, C.c_long, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.edo_fit_mle_groups.restype = C.c_int
         L.edo_fit_mle_cov.argtypes = [_ip, _ip, _dp, C.c_long, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -162,6 +164,14 @@ def fit_mle(test, ref):
     test = _i32(test); ref = _i32(ref)
     phi, p, ll = C.c_double(), C.c_double(), C.c_double()
     it = lib().edo_fit_mle(test, ref, test.size, C.byref(phi), C.byref(p), C.byref(ll))
+    return phi.value, p.value, ll.value, it
+
+
+def fit_mle_hist(test, ref):
+    """fit_mle on sufficient statistics (sums over distinct count values): same estimator, ~100x faster on long columns."""
+    test = _i32(test); ref = _i32(ref)
+    phi, p, ll = C.c_double(), C.c_double(), C.c_double()
+    it = lib().edo_fit_mle_hist(test, ref, test.size, C.byref(phi), C.byref(p), C.byref(ll))
     return phi.value, p.value, ll.value, it
 
 

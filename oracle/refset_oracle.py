@@ -48,6 +48,16 @@ def get_power_betabinom(size, my_phi, my_p, my_alt_p):
     return float(np.sum(pr * (np.log10(np.e) * (la - l0))))
 
 
+def r_seq_thin(length, n_reduced):
+    """0-based positions of x[seq(1, length, length / n_reduced)]: R's seq.default for a fractional `by` computes
+    n <- as.integer((to - from) / by + 1e-10) and from + (0:n) * by, clipped with pmin(., to); fractional subscripts
+    truncate (R/optimize_reference_set.R:86)."""
+    by = length / n_reduced
+    n = int((length - 1.0) / by + 1e-10)
+    x = np.minimum(1.0 + np.arange(n + 1, dtype=np.float64) * by, float(length))
+    return x.astype(np.int64) - 1
+
+
 def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_reduced=0):
     """Returns dict(order, correlations, expected_BF, phi, RatioSd, mean_p, median_depth, n_chosen, n_bins).
     Arrays are in the reference's row order (decreasing correlation); entries the R loop never reaches are NaN."""
@@ -61,13 +71,7 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
     q = r_quantile(total[total > 30], 0.9)                                # :80
     sel = np.where((total > 30) & (L >= r_quantile(L, 0.05)) & (L <= r_quantile(L, 0.95)) & (total < q))[0]   # :82-85
     if 0 < n_bins_reduced < sel.size:                                     # :86
-        step = sel.size / n_bins_reduced
-        pos = []
-        v = 1.0
-        while v <= sel.size + 1e-10:
-            pos.append(int(v) - 1)
-            v += step
-        sel = sel[np.array(pos)]
+        sel = sel[r_seq_thin(sel.size, n_bins_reduced)]
     test = test[sel]; refs = refs[sel]; L = L[sel]
     n = sel.size
     w = test / (L * test.sum() / 1e6)
@@ -91,4 +95,67 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
         alt_p = alt_odds / (1 + alt_odds)
         out["expected_BF"][i] = get_power_betabinom(np.round(out["median_depth"][i]), phi, p, alt_p)   # :135-139
     out["n_chosen"] = int(np.nanargmax(out["expected_BF"])) + 1           # :143 which.max
+    return out
+
+
+def select_reference_set_lean(test_counts, reference_counts, bin_length=None, n_bins_reduced=0, raw_prefixes=()):
+    """The same restatement for BASELINE configs[4] sizes (500 000 bins x 2048 references): the count matrix stays int32
+    and is walked in column blocks (the plain version above converts it to float64 whole: 8 GB + copies).  Runs the R
+    loop with its early exit (rows the loop never reaches stay NaN) and, in addition, evaluates the RAW statistics of
+    the cumulative references listed in `raw_prefixes` (0-based row indices; no early exit) -- what
+    ed_select_reference_set_part returns for those rows.  Returns the dict of select_reference_set() plus
+    'raw': {i: dict(phi, mean_p, median_depth, RatioSd, expected_BF)}."""
+    test = np.asarray(test_counts, dtype=np.float64)
+    refs = np.asarray(reference_counts)
+    assert refs.dtype == np.int32 and refs.ndim == 2
+    E, R = refs.shape
+    L = np.ones(E) if bin_length is None else np.asarray(bin_length, dtype=np.float64)
+    total = refs.sum(axis=1, dtype=np.int64).astype(np.float64) + test
+    q = r_quantile(total[total > 30], 0.9)
+    sel = np.where((total > 30) & (L >= r_quantile(L, 0.05)) & (L <= r_quantile(L, 0.95)) & (total < q))[0]
+    if 0 < n_bins_reduced < sel.size:
+        sel = sel[r_seq_thin(sel.size, n_bins_reduced)]
+    test = test[sel]; L = L[sel]
+    refs = refs[sel]                                                      # int32 (n, R)
+    n = sel.size
+    w = test / (L * test.sum() / 1e6)
+    corr = np.empty(R)
+    for c0 in range(0, R, 64):
+        blk = refs[:, c0:c0 + 64].astype(np.float64)
+        for j in range(blk.shape[1]):
+            x = blk[:, j]
+            corr[c0 + j] = np.corrcoef(x / (L * x.sum() / 1e6), w)[0, 1]
+    order = np.argsort(-corr, kind="stable")
+    out = {k: np.full(R, np.nan) for k in ("expected_BF", "phi", "RatioSd", "mean_p", "median_depth")}
+    out.update(order=order, correlations=corr[order], n_bins=int(n), raw={})
+    want_raw = set(int(i) for i in raw_prefixes)
+    last_raw = max(want_raw) if want_raw else -1
+    ti = test.astype(np.int32)
+
+    def stats(reference):
+        phi, p, _, _ = eo.fit_mle_hist(ti, reference.astype(np.int32))    # the long-double MLE on sufficient statistics
+        med = float(np.median(reference))
+        rsd = float(np.mean(np.sqrt(1 + (test + reference - 1) * phi)))
+        alt_odds = p / (1 - p) * 0.5
+        bf = get_power_betabinom(np.round(med), phi, p, alt_odds / (1 + alt_odds))
+        return phi, p, med, rsd, bf
+
+    reference = np.zeros(n)
+    in_loop = True
+    for i in range(R):
+        if not in_loop and i > last_raw:
+            break
+        reference = reference + refs[:, order[i]]
+        if not in_loop and i not in want_raw:
+            continue
+        phi, p, med, rsd, bf = stats(reference)
+        if i in want_raw:
+            out["raw"][i] = dict(phi=phi, mean_p=p, median_depth=med, RatioSd=rsd, expected_BF=bf)
+        if in_loop:
+            out["phi"][i], out["mean_p"][i], out["median_depth"][i], out["RatioSd"][i] = phi, p, med, rsd
+            if i + 1 > 2 and p < 0.05:
+                in_loop = False                                           # :130 break: expected.BF[i] stays NA
+                continue
+            out["expected_BF"][i] = bf
+    out["n_chosen"] = int(np.nanargmax(out["expected_BF"])) + 1
     return out

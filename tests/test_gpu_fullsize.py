@@ -122,3 +122,57 @@ def test_subset_of_samples_gives_the_same_columns(full):
     assert np.array_equal(b.calls(), sub)
     b.close()
     torch.cuda.synchronize()
+
+
+# ---- BASELINE.json configs[3]: the whole 200 000 x 8192 cohort on ONE GPU (1.6e9 cells, ~70 GB of HBM, cell indices
+# ---- beyond 2^31) -- what 8 GPUs each do an eighth of
+def test_config3_whole_cohort_200k_x_8192_on_one_gpu(edlib, oracle):
+    torch = pytest.importorskip("torch")
+    from exomedepth_amd import synth
+    S8 = 8192
+    dev = torch.device("cuda", 0)
+    chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
+    test, ref, p, phi = synth.counts_torch(chrom_off, S8, dev, seed=20250699)
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S8)
+    try:
+        phi_f = torch.empty(S8, dtype=torch.float64, device=dev)
+        p_f = torch.empty(S8, dtype=torch.float64, device=dev)
+        batch.fit(test, ref, phi_f, p_f)
+        batch.run(test, ref, phi_f, p_f)
+        calls = batch.calls()
+        assert batch.n_gsl_errors() == 0
+        # the whole likelihood matrix (39 GB) against the per-cell evaluation, on the device
+        ncmp, nbad, first = batch.verify_emissions(test, ref, phi_f, p_f)
+        assert (ncmp, nbad) == (3 * E * S8, 0), first
+        path = batch.path()
+        phi_h, p_h = phi_f.cpu().numpy(), p_f.cpu().numpy()
+        for s in (0, 4095, 4096, 8191):                                  # whole columns against the checker
+            t = test[:, s].cpu().numpy(); r = ref[:, s].cpu().numpy()
+            ophi, op, _, _ = oracle.fit_mle_hist(t, r)
+            assert abs(phi_h[s] - ophi) < 1e-7 * ophi and abs(p_h[s] - op) < 1e-8 * op, ("fit", s)
+            ell, nerr = oracle.get_loglike_matrix(phi_h[s], p_h[s], t + r, t, 1.0, oracle.PORTABLE)
+            epath, ecalls = oracle.callcnvs(ell, chrom_off, start, end)
+            assert nerr == 0 and np.array_equal(path[:, s].astype(np.int8), epath), ("path", s)
+            mine = calls[calls["sample"] == s]
+            assert len(mine) == len(ecalls)
+            for k, name in enumerate(("start_exon", "end_exon", "type", "nexons")):
+                assert np.array_equal(mine[name] + (1 if k < 2 else 0), ecalls[:, k].astype(np.int64)), (name, s)
+        # properties over all 1.6e9 cells: the call table is the run-length encoding of the path ...
+        nz = path != 0
+        ends = nz.copy()
+        ends[:-1] &= (path[:-1] != path[1:])
+        last = np.asarray(chrom_off[1:]) - 1
+        ends[last] = nz[last]
+        assert int(ends.sum()) == len(calls)
+        assert np.array_equal(np.bincount(calls["sample"], minlength=S8), ends.sum(axis=0))
+        # ... and a slab of columns run as its own batch gives the same columns (independence of samples)
+        cols = slice(5120, 5184)
+        b = edlib.Batch(plan, 64)
+        b.run(test[:, cols].contiguous(), ref[:, cols].contiguous(), phi_f[cols].contiguous(), p_f[cols].contiguous())
+        assert np.array_equal(b.path(), path[:, cols])
+        b.close()
+    finally:
+        batch.close(); plan.close()
+        del test, ref
+        torch.cuda.empty_cache()

@@ -105,3 +105,65 @@ def test_get_power_betabinom_standalone(edlib):
     assert isinstance(edlib.get_power_betabinom(200, 0.1, 0.2, 0.6), float)
     with pytest.raises(NotImplementedError):
         edlib.get_power_betabinom(200, 0.1, 0.2, 0.6, theory=True)
+
+
+# ---- BASELINE.json configs[4]: select.reference.set, 500 000 bins x 2048 candidate references ----
+def test_config4_select_reference_set_500k_x_2048(edlib, oracle):
+    """Full size through ed_select_reference_set: against the restated R code (memory-lean form, the checker's long-double
+    MLE) on every row the R loop reaches before its early exit, on the RAW statistics of a strided set of deeper
+    cumulative references, and the two-share decomposition of the multi-GPU path merging to the whole bit for bit."""
+    torch = pytest.importorskip("torch")
+    from oracle import refset_oracle as ro
+    Eb, R = 500_000, 2048
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    lam = torch.empty(Eb, device=dev, dtype=torch.float32).log_normal_(float(np.log(60.0)), 0.7, generator=g)
+    sig = torch.linspace(0.02, 0.4, R, device=dev)[torch.randperm(R, device=dev, generator=g)]
+    test = torch.poisson(lam, generator=g).to(torch.int32)
+    refs = torch.empty((Eb, R), device=dev, dtype=torch.int32)
+    for lo in range(0, Eb, 16384):
+        hi = min(lo + 16384, Eb)
+        noise = torch.exp(torch.randn((hi - lo, R), device=dev, generator=g) * sig[None, :])
+        refs[lo:hi] = torch.poisson(lam[lo:hi, None] * noise, generator=g).to(torch.int32)
+    length = torch.randint(60, 600, (Eb,), device=dev, generator=g).cpu().numpy().astype(np.float64)
+    whole = edlib.select_reference_set(test, refs, bin_length=length)
+    st = whole["summary.stats"]
+    raw_rows = (0, 1, 2, 7, 19, 20, 21, 63, 257)
+    exp = ro.select_reference_set_lean(test.cpu().numpy(), refs.cpu().numpy(), bin_length=length, raw_prefixes=raw_rows)
+    assert whole["n.bins"] == exp["n_bins"] and exp["n_bins"] > 300_000
+    assert np.array_equal(st["ref_index"], exp["order"])
+    assert np.allclose(st["correlation"], exp["correlations"], rtol=0, atol=1e-12)
+    reached = ~np.isnan(exp["phi"])
+    assert 3 <= reached.sum() < 100                                       # the loop's early exit (:130) triggers: mean.p < 0.05
+    for mine, theirs, tol in (("phi", "phi", 1e-7), ("mean_p", "mean_p", 1e-8), ("median_depth", "median_depth", 0.0),
+                              ("ratio_sd", "RatioSd", 1e-8), ("expected_BF", "expected_BF", 1e-7)):
+        a, b = st[mine], exp[theirs]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), mine
+        m = ~np.isnan(b)
+        assert np.all(np.abs(a[m] - b[m]) <= tol * np.abs(b[m])), (mine, a[m], b[m])
+    assert len(whole["reference.choice"]) == exp["n_chosen"] and int(np.argmax(st["selected"])) == exp["n_chosen"] - 1
+    # raw statistics of deeper prefixes + the decomposition over two ranks
+    cut = R // 2
+    a = edlib.select_reference_set(test, refs, bin_length=length, prefix_window=(0, cut))
+    b = edlib.select_reference_set(test, refs, bin_length=length, prefix_window=(cut, R))
+    merged = a["summary.stats"].copy()
+    merged[cut:] = b["summary.stats"][cut:]
+    for i in raw_rows:
+        want = exp["raw"][i]
+        row = merged[i]
+        tol_phi = max(1e-7, 1e-13 / want["phi"] ** 2)                     # DESIGN 4.5: binary64 resolves phi to ~2e-14 / phi^2
+        assert abs(row["phi"] - want["phi"]) <= tol_phi * want["phi"], (i, row, want)
+        assert abs(row["mean_p"] - want["mean_p"]) <= 1e-8 * want["mean_p"] and row["median_depth"] == want["median_depth"], (i, row, want)
+        assert abs(row["ratio_sd"] - want["RatioSd"]) <= 1e-7 * want["RatioSd"], (i, row, want)
+        assert abs(row["expected_BF"] - want["expected_BF"]) <= max(1e-7, 10 * tol_phi) * abs(want["expected_BF"]), (i, row, want)
+    assert np.all(np.isfinite(merged["phi"])) and np.all(np.isfinite(merged["expected_BF"]))   # all 2048 prefixes were fitted
+    fin = edlib.refset_finalize(merged)
+    for name in st.dtype.names:
+        x, y = fin["summary.stats"][name], st[name]
+        assert np.array_equal(x.view("u4" if x.dtype.itemsize == 4 else "u8"), y.view("u4" if y.dtype.itemsize == 4 else "u8")), name
+    assert fin["reference.choice"] == whole["reference.choice"]
+    # n.bins.reduced = 10000, the vignette's setting: R's seq() thinning (ADVICE r1)
+    red = edlib.select_reference_set(test, refs, bin_length=length, n_bins_reduced=10000)
+    assert red["n.bins"] == len(ro.r_seq_thin(exp["n_bins"], 10000))
+    del refs
+    torch.cuda.empty_cache()

@@ -77,3 +77,44 @@ def test_count_container_roundtrip(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         io.write_counts(path, chrom, start, end, counts + 0.5)
+
+
+def test_bin_thinning_follows_r_seq_semantics():
+    """selected[seq(1, length(selected), length(selected) / n.bins.reduced)] (reference R/optimize_reference_set.R:86).
+    R's seq.default computes from + (0:n) * by with n = as.integer((to - from) / by + 1e-10), clips with pmin(., to), and
+    a fractional subscript truncates.  Accumulating the step instead (pos += by) picks different bins for about a quarter
+    of the (length, n) pairs: length 50, n 24 gives position 25 instead of R's 26 at k = 12 (1-based)."""
+    import ctypes as C
+    from fractions import Fraction
+    from exomedepth_amd import _lib
+    L = _lib.lib()
+
+    def lib_positions(length, nred):
+        out = np.zeros(nred + 2, dtype=np.int64)
+        n = C.c_int64(0)
+        _lib.check(L.ed_refset_thin_positions(length, nred, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value]
+
+    got = lib_positions(50, 24)
+    assert got[12] + 1 == 26                   # R: seq(1, 50, 50/24)[13] = 26.000000000000004 -> 26
+    assert got[0] == 0 and got[-1] <= 49 and np.all(np.diff(got) >= 1)
+    n_differs_from_accumulation = 0
+    rng = np.random.default_rng(0)
+    for _ in range(400):
+        length = int(rng.integers(5, 200000)); nred = int(rng.integers(1, length))
+        by = np.float64(length) / np.float64(nred)
+        n = int((np.float64(length) - 1.0) / by + 1e-10)
+        want = (np.minimum(1.0 + np.arange(n + 1, dtype=np.float64) * by, float(length))).astype(np.int64) - 1
+        got = lib_positions(length, nred)
+        assert np.array_equal(got, want), (length, nred)
+        # exact rational positions differ from the binary64 ones only where k * by rounds across an integer
+        exact = [int(1 + Fraction(k * length, nred)) - 1 for k in range(min(n + 1, 50))]
+        assert all(abs(int(a) - b) <= 1 for a, b in zip(got[:50], exact))
+        acc, v = [], 1.0
+        while v <= length + 1e-10:
+            acc.append(int(v) - 1); v += by
+        n_differs_from_accumulation += (len(acc) != len(got)) or bool(np.any(np.array(acc) != got))
+    assert n_differs_from_accumulation > 20    # the old accumulation really was a different function
+    from oracle import refset_oracle
+    for length, nred in ((50, 24), (9000, 700), (123457, 10000)):
+        assert np.array_equal(refset_oracle.r_seq_thin(length, nred), lib_positions(length, nred))

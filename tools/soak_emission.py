@@ -50,7 +50,8 @@ def soak(seconds=60.0, seed=1, regimes=("small", "tiny", "exome"), log=print, ta
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     t0 = time.time()
-    stats = {r: {"batches": 0, "runs": 0, "cells": 0, "values": 0, "mismatch": 0} for r in regimes}
+    stats = {r: {"batches": 0, "runs": 0, "cells": 0, "values": 0, "mismatch": 0, "s_create": 0.0, "s_counts": 0.0, "s_run_verify": 0.0}
+             for r in regimes}
     events = []
     it = 0
     while time.time() - t0 < seconds and (target_cells is None or sum(v["cells"] for v in stats.values()) < target_cells):
@@ -65,25 +66,37 @@ def soak(seconds=60.0, seed=1, regimes=("small", "tiny", "exome"), log=print, ta
             else:
                 S = int(rng.choice([64, 448, 512, 513, 576, 1000, 1024, 2048]))
                 E = int(min(max_batch_cells / S, rng.integers(2000, 120000)))
-                runs = 6
+                runs = 30
             C = int(rng.integers(1, 6))
             chrom_off, start, end = _design(E, min(C, E), rng)
+            tc = time.time()
             plan = ed.Plan(chrom_off, start, end, float(rng.choice([1e-4, 1e-2])), float(rng.choice([5e4, 2e3])))
             batch = ed.Batch(plan, S)
-            # counts: exon depth x per-sample factors, Poisson; a fifth of the cells without reads
-            depth = float(rng.uniform(1.0, 10.0)) if regime != "exome" else float(rng.choice([40.0, 100.0, 300.0]))
-            lam_e = depth * torch.exp(0.8 * torch.randn(E, 1, device=dev, dtype=torch.float32, generator=gen))
-            f_t = torch.empty(1, S, device=dev, dtype=torch.float32).uniform_(0.05, 1.0, generator=gen)
-            f_r = torch.empty(1, S, device=dev, dtype=torch.float32).uniform_(0.3, 6.0, generator=gen)
-            test = torch.poisson(lam_e * f_t, generator=gen)
-            ref = torch.poisson(lam_e * f_r, generator=gen)
-            if rng.random() < 0.7:
-                dead = torch.rand(E, S, device=dev, generator=gen) < 0.2
-                test[dead] = 0
-                ref[dead] = 0
-            test = test.to(torch.int32).contiguous()
-            ref = ref.to(torch.int32).contiguous()
-            for _ in range(runs):
+            stats[regime]["s_create"] += time.time() - tc
+
+            def fresh_counts():
+                # counts: exon depth x per-sample factors, Poisson; a fifth of the cells without reads
+                depth = float(rng.uniform(1.0, 10.0)) if regime != "exome" else float(rng.choice([40.0, 100.0, 300.0]))
+                lam_e = depth * torch.exp(0.8 * torch.randn(E, 1, device=dev, dtype=torch.float32, generator=gen))
+                f_t = torch.empty(1, S, device=dev, dtype=torch.float32).uniform_(0.05, 1.0, generator=gen)
+                f_r = torch.empty(1, S, device=dev, dtype=torch.float32).uniform_(0.3, 6.0, generator=gen)
+                t = torch.poisson(lam_e * f_t, generator=gen)
+                r = torch.poisson(lam_e * f_r, generator=gen)
+                if rng.random() < 0.7:
+                    dead = torch.rand(E, S, device=dev, generator=gen) < 0.2
+                    t[dead] = 0
+                    r[dead] = 0
+                t, r = t.to(torch.int32).contiguous(), r.to(torch.int32).contiguous()
+                torch.cuda.synchronize()
+                return t, r
+            tc = time.time()
+            test, ref = fresh_counts()
+            stats[regime]["s_counts"] += time.time() - tc
+            for irun in range(runs):
+                if irun and irun % 6 == 0:
+                    tc = time.time()
+                    test, ref = fresh_counts()      # (the batch and its buffers stay: only the tiny regime churns them)
+                    stats[regime]["s_counts"] += time.time() - tc
                 if regime == "exome":
                     phi = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.001, 0.02, generator=gen)
                     p = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.03, 0.3, generator=gen)
@@ -91,9 +104,11 @@ def soak(seconds=60.0, seed=1, regimes=("small", "tiny", "exome"), log=print, ta
                     phi = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.05, 0.5, generator=gen)
                     p = torch.empty(S, device=dev, dtype=torch.float64).uniform_(0.02, 0.6, generator=gen)
                 mixture = float(rng.choice([1.0, 1.0, 1.0, 0.4]))
+                tc = time.time()
                 batch.run(test, ref, phi, p, mixture=mixture)
                 ncmp, nbad, first = batch.verify_emissions(test, ref, phi, p, mixture=mixture, cap=16)
                 st = stats[regime]
+                st["s_run_verify"] += time.time() - tc
                 st["runs"] += 1; st["cells"] += E * S; st["values"] += ncmp; st["mismatch"] += nbad
                 assert ncmp == 3 * E * S, (ncmp, E, S)
                 if nbad:
@@ -118,7 +133,9 @@ def soak(seconds=60.0, seed=1, regimes=("small", "tiny", "exome"), log=print, ta
                     events.append({"regime": regime, "E": E, "S": S, "C": C, "values": int(nbad), "first": first, "again": again,
                                    "case": os.path.basename(fn)})
             stats[regime]["batches"] += 1
+            tc = time.time()
             batch.close(); plan.close()
+            stats[regime]["s_create"] += time.time() - tc
     total = {k: sum(v[k] for v in stats.values()) for k in ("batches", "runs", "cells", "values", "mismatch")}
     return {"seconds": time.time() - t0, "seed": seed, "per_regime": stats, "total": total, "events": events,
             "serialize_kernel": os.environ.get("AMD_SERIALIZE_KERNEL", ""), "library": os.path.basename(ed.LIB_PATH)}
