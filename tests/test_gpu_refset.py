@@ -119,7 +119,9 @@ def test_config4_select_reference_set_500k_x_2048(edlib, oracle):
     g = torch.Generator(device=dev); g.manual_seed(5)
     lam = torch.empty(Eb, device=dev, dtype=torch.float32).log_normal_(float(np.log(60.0)), 0.7, generator=g)
     sig = torch.linspace(0.02, 0.4, R, device=dev)[torch.randperm(R, device=dev, generator=g)]
-    test = torch.poisson(lam, generator=g).to(torch.int32)
+    # the test sample carries its own per-bin distortion (8 %): the dispersion of test vs cumulative reference then stays
+    # at exome-like values (phi ~ 1e-3 - 1e-4) however many references are summed, instead of decaying to a binomial
+    test = torch.poisson(lam * torch.exp(0.08 * torch.randn(Eb, device=dev, generator=g)), generator=g).to(torch.int32)
     refs = torch.empty((Eb, R), device=dev, dtype=torch.int32)
     for lo in range(0, Eb, 16384):
         hi = min(lo + 16384, Eb)
@@ -135,12 +137,14 @@ def test_config4_select_reference_set_500k_x_2048(edlib, oracle):
     assert np.allclose(st["correlation"], exp["correlations"], rtol=0, atol=1e-12)
     reached = ~np.isnan(exp["phi"])
     assert 3 <= reached.sum() < 100                                       # the loop's early exit (:130) triggers: mean.p < 0.05
-    for mine, theirs, tol in (("phi", "phi", 1e-7), ("mean_p", "mean_p", 1e-8), ("median_depth", "median_depth", 0.0),
-                              ("ratio_sd", "RatioSd", 1e-8), ("expected_BF", "expected_BF", 1e-7)):
+    tol_phi_rows = np.maximum(1e-7, 1e-13 / np.where(reached, exp["phi"], 1.0) ** 2)   # binary64 resolves phi to ~2e-14 / phi^2
+    assert np.all(exp["phi"][reached] > 1e-5)
+    for mine, theirs, tol in (("phi", "phi", tol_phi_rows), ("mean_p", "mean_p", 1e-8), ("median_depth", "median_depth", 0.0),
+                              ("ratio_sd", "RatioSd", 1e-7), ("expected_BF", "expected_BF", 10 * tol_phi_rows)):
         a, b = st[mine], exp[theirs]
         assert np.array_equal(np.isnan(a), np.isnan(b)), mine
         m = ~np.isnan(b)
-        assert np.all(np.abs(a[m] - b[m]) <= tol * np.abs(b[m])), (mine, a[m], b[m])
+        assert np.all(np.abs(a[m] - b[m]) <= (tol[m] if np.ndim(tol) else tol) * np.abs(b[m])), (mine, a[m], b[m])
     assert len(whole["reference.choice"]) == exp["n_chosen"] and int(np.argmax(st["selected"])) == exp["n_chosen"] - 1
     # raw statistics of deeper prefixes + the decomposition over two ranks
     cut = R // 2
