@@ -20,6 +20,19 @@ def hipcc():
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources (the files libedcore.so is built from).  rocprofv3 summaries under profiles/ are
+    stamped with it (tools/profile_round.sh); bench.py only quotes counter-derived figures from a profile whose stamp
+    equals the tree's, so a changed kernel can never be described by a stale profile."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        p = os.path.join(CSRC, d)
+        if os.path.exists(p):
+            h.update(d.encode()); h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True

@@ -197,14 +197,16 @@ class Batch:
         self.plan = plan
         self.n_samples = int(n_samples)
         self.handle = C.c_void_p()
-        self._keep = []
+        self._keep_run = []   # device temporaries uploaded for the last run*(): call_info() / verify read the run's inputs
+        self._keep_fit = []   # ... for the last fit*() (outputs may be read by the caller after the call)
         check(lib().ed_batch_create(C.byref(self.handle), plan.handle, self.n_samples))
 
     def close(self):
         if self.handle:
             lib().ed_batch_destroy(self.handle)
             self.handle = C.c_void_p()
-        self._keep = []
+        self._keep_run = []
+        self._keep_fit = []
 
     def __del__(self):
         try:
@@ -222,6 +224,15 @@ class Batch:
     def keep_loglik(self, keep=True):
         """Keep (default) or drop the (n_exons, 3, n_samples) likelihood matrix -- 24 bytes per cell of HBM."""
         check(lib().ed_batch_keep_loglik(self.handle, 1 if keep else 0))
+
+    def set_async_tail(self, on=True):
+        """on: run() leaves the Viterbi tail and the call table on streams of the batch instead of joining them into the
+        caller's stream (two batches used alternately then overlap; see ed_batch_set_async_tail)."""
+        check(lib().ed_batch_set_async_tail(self.handle, 1 if on else 0))
+
+    def wait(self, stream=None):
+        """make `stream` wait (on the device) for the last run() of this batch, asynchronous tail included"""
+        check(lib().ed_batch_wait(self.handle, C.c_void_p(stream or 0)))
 
     def set_fit_histograms(self, on=True):
         """fit(): iterate on per-sample count histograms (default; True / 1: geometry picked from the data's depth,
@@ -242,7 +253,7 @@ class Batch:
         pr = _device_pointer(ref, np.int32, keep)
         pp = _device_pointer(phi_out, np.float64, keep)
         pe = _device_pointer(expected_out, np.float64, keep)
-        self._keep = keep
+        self._keep_fit = keep
         check(lib().ed_batch_fit_subset(self.handle, pt, pr, int(by), pp, pe, C.c_void_p(stream or 0)))
 
     def run(self, test, ref, phi, expected, mixture=1.0, stream=None):
@@ -253,7 +264,7 @@ class Batch:
         pr = _device_pointer(ref, np.int32, keep)
         pp = _device_pointer(phi, np.float64, keep)
         pe = _device_pointer(expected, np.float64, keep)
-        self._keep = keep  # keep temporaries alive until the next run
+        self._keep_run = keep  # keep temporaries alive until the next run
         check(lib().ed_batch_run(self.handle, pt, pr, pp, pe, float(mixture), C.c_void_p(stream or 0)))
 
     def fit_bins(self, test, ref, phi_bins, phi_bins_out, edges_out, expected_out, stream=None):
@@ -267,7 +278,7 @@ class Batch:
         pp = _device_pointer(phi_bins_out, np.float64, keep)
         pg = _device_pointer(edges_out, np.float64, keep)
         pe = _device_pointer(expected_out, np.float64, keep)
-        self._keep = keep
+        self._keep_fit = keep
         check(lib().ed_batch_fit_bins(self.handle, pt, pr, int(phi_bins), pp, pg, pe, C.c_void_p(stream or 0)))
 
     def run_bins(self, test, ref, phi_bins, phi_bins_dev, edges_dev, expected, mixture=1.0, stream=None):
@@ -278,7 +289,7 @@ class Batch:
         pp = _device_pointer(phi_bins_dev, np.float64, keep)
         pg = _device_pointer(edges_dev, np.float64, keep)
         pe = _device_pointer(expected, np.float64, keep)
-        self._keep = keep
+        self._keep_run = keep
         check(lib().ed_batch_run_bins(self.handle, pt, pr, int(phi_bins), pp, pg, pe, float(mixture), C.c_void_p(stream or 0)))
 
     def phi_linear(self, ref, phi_bins, phi_bins_dev, edges_dev):
@@ -309,7 +320,7 @@ class Batch:
         px = _device_pointer(X, np.float64, keep) if K > 0 else None
         pb = _device_pointer(beta_out, np.float64, keep)
         pp = _device_pointer(phi_out, np.float64, keep)
-        self._keep = keep
+        self._keep_fit = keep
         check(lib().ed_batch_fit_cov(self.handle, pt, pr, px, K, pb, pp, C.c_void_p(stream or 0)))
 
     def run_cov(self, test, ref, X, beta, phi, mixture=1.0, stream=None):
@@ -321,7 +332,7 @@ class Batch:
         px = _device_pointer(X, np.float64, keep) if K > 0 else None
         pb = _device_pointer(beta, np.float64, keep)
         pp = _device_pointer(phi, np.float64, keep)
-        self._keep = keep
+        self._keep_run = keep
         check(lib().ed_batch_run_cov(self.handle, pt, pr, px, K, pb, pp, float(mixture), C.c_void_p(stream or 0)))
 
     def expected_cov(self, X, beta):
@@ -391,6 +402,13 @@ class Batch:
         L = lib()
         return {"loglik": L.ed_batch_loglik(self.handle), "path": L.ed_batch_path(self.handle),
                 "calls": L.ed_batch_calls(self.handle)}
+
+    def stage_ms_total(self):
+        """(dict of stage -> summed milliseconds, timed runs, timed fits) since enable_timing()"""
+        ms = (C.c_double * 5)()
+        nr, nf = C.c_int64(0), C.c_int64(0)
+        check(lib().ed_batch_stage_ms_total(self.handle, ms, C.byref(nr), C.byref(nf)))
+        return dict(zip(self.STAGES, [float(v) for v in ms])), nr.value, nf.value
 
     def stage_ms(self):
         ms = (C.c_float * 5)()

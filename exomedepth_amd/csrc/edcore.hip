@@ -1461,7 +1461,16 @@ struct ed_batch {
   ed_call* d_calls = nullptr;
   struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
   int64_t calls_cap = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;         // where the results of the last run become available: the caller's stream, or `fin`
+  hipStream_t fit_stream = nullptr;     // stream of the last ed_batch_fit (its own timing events only)
+  // Asynchronous tail (ed_batch_set_async_tail): the caller's stream carries the emissions only; the Viterbi groups run on
+  // the side streams as before, and what follows them (call counts -> scan -> call records) runs on `fin` instead of
+  // being joined back into the caller's stream.  `done_ev` marks the end of the run; the next ed_batch_run on this batch
+  // waits for it (the buffers are reused), the accessors synchronise on it.  With two batches used alternately on ONE
+  // stream, batch N's Viterbi tail and call table then run underneath batch N+1's emissions.
+  bool async_tail = false;
+  hipStream_t fin = nullptr;
+  hipEvent_t done_ev = nullptr, fork_ev = nullptr;
   const int32_t* last_test = nullptr;   // inputs of the last ed_batch_run (for ed_batch_copy_call_info)
   const int32_t* last_ref = nullptr;
   const double* last_expected = nullptr;
@@ -1476,6 +1485,8 @@ struct ed_batch {
   bool timing = false;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_run_times = false, have_fit_time = false;
+  double stage_total[5] = {0, 0, 0, 0, 0};   // sums of the stage times of all timed runs / fits since timing was enabled
+  int64_t n_runs_timed = 0, n_fits_timed = 0;
 };
 
 // log-transition table of one chain: for padded positions pos[0..n-1], gaps i=1..n-1
@@ -1953,13 +1964,65 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->join_ev) if (e) (void)hipEventDestroy(e);
   for (auto& sd : b->sides) if (sd) (void)hipStreamDestroy(sd);
+  if (b->fin) (void)hipStreamDestroy(b->fin);
+  if (b->done_ev) (void)hipEventDestroy(b->done_ev);
+  if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
   delete b;
+}
+
+// Add the stage times of the last timed run / fit to the running totals (called before their events are recorded
+// again, and by ed_batch_stage_ms_total).  The events belong to work issued earlier on this batch; with two batches
+// used alternately that work is a whole step old, so the synchronisation does not stall the pipeline.
+static int fold_stage_times(ed_batch* b)
+{
+  if (b->have_run_times) {
+    HIP_TRY(hipEventSynchronize(b->ev[4]));
+    for (int i = 0; i < 4; ++i) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
+      b->stage_total[i] += ms;
+    }
+    ++b->n_runs_timed;
+    b->have_run_times = false;
+  }
+  if (b->have_fit_time) {
+    HIP_TRY(hipEventSynchronize(b->ev[6]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b->ev[5], b->ev[6]));
+    b->stage_total[4] += ms;
+    ++b->n_fits_timed;
+    b->have_fit_time = false;
+  }
+  return ED_OK;
 }
 
 ED_EXPORT int ed_batch_enable_timing(ed_batch* b, int enable)
 {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->timing = enable != 0;
+  b->have_run_times = b->have_fit_time = false;
+  for (double& t : b->stage_total) t = 0.0;
+  b->n_runs_timed = b->n_fits_timed = 0;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_set_async_tail(ed_batch* b, int on)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  HIP_TRY(hipSetDevice(b->plan->device));
+  if (on && !b->fin) {
+    HIP_TRY(hipStreamCreateWithFlags(&b->fin, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+  }
+  b->async_tail = on != 0;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_wait(ed_batch* b, void* stream_)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  if (b->ran && b->async_tail && b->done_ev) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, b->done_ev, 0));
   return ED_OK;
 }
 
@@ -1996,7 +2059,11 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   const ed_plan* p = b->plan;
   const int64_t E = p->E, S = b->S;
   const int32_t C = p->C;
-  b->stream = st;
+  const bool async = b->async_tail && !b->fused;
+  hipStream_t tail = async ? b->fin : st;   // where the call table is built and the results become available
+  if (b->timing) { if (int rc = fold_stage_times(b)) return rc; }
+  if (async && b->ran) HIP_TRY(hipStreamWaitEvent(st, b->done_ev, 0));   // the previous run's tail still reads the buffers
+  b->stream = tail;
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 8, st));
@@ -2072,18 +2139,23 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       HIP_TRY(hipEventRecord(b->join_ev[g], side));
     }
     if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));   // all emissions issued and done on the main stream
-    for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) HIP_TRY(hipStreamWaitEvent(st, b->join_ev[g], 0));
+    if (async) {   // orders `tail` after everything this run put on the caller's stream, groups or not
+      HIP_TRY(hipEventRecord(b->fork_ev, st));
+      HIP_TRY(hipStreamWaitEvent(tail, b->fork_ev, 0));
+    }
+    for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) HIP_TRY(hipStreamWaitEvent(tail, b->join_ev[g], 0));
   }
   if (b->fused && C > 0 && cells > 0 && p->max_words > 0)   // (the two-kernel path writes the byte path in k_tb_paths)
     hipLaunchKernelGGL(k_path_expand, dim3((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)C), dim3(256),
                        0, st, b->d_ppath, p->d_chrom_off, p->d_tile_off, S, b->d_path);
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, b->d_counts, (C > 0 && cells > 0) ? S * C : 0,
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], tail));
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, tail, b->d_counts, (C > 0 && cells > 0) ? S * C : 0,
                      b->d_offsets, b->d_total);
   if (C > 0 && cells > 0)
-    hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave, kCallSeg), 0, st,
+    hipLaunchKernelGGL(k_calls_fill, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)C), dim3(kWave, kCallSeg), 0, tail,
                        b->d_ppath, p->d_chrom_off, p->d_tile_off, S, C, b->d_offsets, b->d_counts, b->d_calls, b->calls_cap);
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], tail));
+  if (async) HIP_TRY(hipEventRecord(b->done_ev, tail));
   HIP_TRY(hipGetLastError());
   b->ran = true;
   b->have_run_times = b->timing;
@@ -2229,7 +2301,8 @@ ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int3
     if (!b->fitw) return ed_fail(ED_ERR_NOMEM, "out of host memory");
     if (int rc = b->fitw->alloc(E, S)) return rc;
   }
-  b->stream = st;
+  b->fit_stream = st;
+  if (b->timing) { if (int rc = fold_stage_times(b)) return rc; }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
   const int64_t rows = (E - 1) / by + 1;
   if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist)) return rc;
@@ -2404,6 +2477,16 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
   *n_compared = (int64_t)c[1];
   const int64_t k = std::min<int64_t>((int64_t)c[2], cap);
   if (k > 0) HIP_TRY(hipMemcpy(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), hipMemcpyDeviceToHost));
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_stage_ms_total(ed_batch* b, double ms_total[5], int64_t* n_runs, int64_t* n_fits)
+{
+  if (!b || !ms_total) return ed_fail(ED_ERR_INVALID, "NULL argument");
+  if (int rc = fold_stage_times(b)) return rc;
+  for (int i = 0; i < 5; ++i) ms_total[i] = b->stage_total[i];
+  if (n_runs) *n_runs = b->n_runs_timed;
+  if (n_fits) *n_fits = b->n_fits_timed;
   return ED_OK;
 }
 

@@ -18,13 +18,15 @@ def shard_bounds(n_samples, rank, world_size):
 
 
 def gather_call_tables(local_calls, sample_offset, group=None, dst=0):
-    """Gather per-rank call tables on `dst`.
+    """Gather per-rank call tables on `dst` -- the path's only collective (RCCL over xGMI: KBs per rank).
 
-    local_calls: torch int32 tensor [n_local, 6] (sample, chrom, start_exon, end_exon, type, nexons)
-    on the backend's device; `sample` is local to the rank and is shifted by sample_offset so that the
-    gathered table indexes the global sample axis.  Returns the concatenated [n_total, 6] tensor on
-    `dst` (ordered by rank, hence by global sample) and None elsewhere.  Variable lengths are handled
-    by one all_gather of the counts followed by one padded all_gather of the rows."""
+    local_calls: torch int32 tensor [n_local, 6] (sample, chrom, start_exon, end_exon, type, nexons) on the backend's
+    device (device_call_table() gives it straight from a batch's device-resident table); `sample` is local to the rank
+    and is shifted by sample_offset so that the gathered table indexes the global sample axis.  Returns the
+    concatenated [n_total, 6] tensor on `dst` (ordered by rank, hence by global sample) and None elsewhere.
+    One `gather` of the row counts to `dst`, then every other rank sends exactly its rows to `dst` (point to point:
+    xGMI is a full mesh, each sender has its own link) -- nothing is padded and nothing goes to ranks that do not
+    need it."""
     import torch
     import torch.distributed as dist
 
@@ -35,17 +37,42 @@ def gather_call_tables(local_calls, sample_offset, group=None, dst=0):
     if rows.numel():
         rows[:, 0] += int(sample_offset)
     n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    padded = torch.zeros((cap, 6), dtype=torch.int32, device=dev)
-    padded[: rows.shape[0]] = rows
-    bufs = [torch.zeros((cap, 6), dtype=torch.int32, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)] if rank == dst else None
+    dist.gather(n_local, counts, dst=dst, group=group)
     if rank != dst:
+        if rows.shape[0]:
+            dist.send(rows.contiguous(), dst=dst, group=group)
         return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    parts = []
+    for r in range(world):
+        c = int(counts[r].item())
+        if r == dst:
+            parts.append(rows)
+        elif c:
+            buf = torch.empty((c, 6), dtype=torch.int32, device=dev)
+            dist.recv(buf, src=r, group=group)
+            parts.append(buf)
+    return torch.cat(parts, dim=0) if parts else rows
+
+
+class _DevicePointer:
+    """a raw device buffer as a __cuda_array_interface__ object (so that torch can wrap it without a copy through the host)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), True), "version": 2}
+
+
+def device_call_table(batch):
+    """The call table of the batch's last run as an int32 [n, 6] torch CUDA tensor, copied device-to-device from the
+    library's table (no round trip through the host).  Synchronises the batch (the row count is host data)."""
+    import torch
+
+    n = batch.n_calls()
+    if n == 0:
+        return torch.zeros((0, 6), dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    ptr = batch.device_pointers()["calls"]
+    view = torch.as_tensor(_DevicePointer(ptr, (n, 6), "<i4"), device=torch.device("cuda", torch.cuda.current_device()))
+    return view.clone()
 
 
 def calls_to_tensor(calls_np, device):

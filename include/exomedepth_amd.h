@@ -198,6 +198,19 @@ int ed_batch_keep_loglik(ed_batch* batch, int keep);
  * denominator of per-launch figures in bench.py. */
 int ed_batch_n_emit_launches(const ed_batch* batch);
 
+/* Pipelining consecutive batches.  By default ed_batch_run joins everything it started back into `stream`: the stream is
+ * then blocked until the last Viterbi chains and the call table of this batch are done (~0.5 ms at 200 000 x 1024 during
+ * which the chip is nearly idle).  With ed_batch_set_async_tail(batch, 1) the caller's stream carries the emission
+ * kernels only; the Viterbi groups, the trace-back and the call table finish on streams of the batch, and
+ *   - the accessors below (ed_batch_n_calls, ed_batch_copy_*, ...) wait for them, as before;
+ *   - ed_batch_wait(batch, stream) makes another stream wait for them (device-side, no host synchronisation);
+ *   - the next ed_batch_run on the SAME batch waits for them by itself (its buffers are reused).
+ * Two batches used alternately on one stream, the dispersion fit of the next batch issued on a second stream while the
+ * current one runs, give a two-deep pipeline: fit(N+1) and the tail of N execute underneath the VALU-bound emissions
+ * of N / N+1 (bench.py does exactly this).  Results are unchanged bit for bit.  Not available in fused mode (ignored). */
+int ed_batch_set_async_tail(ed_batch* batch, int on);
+int ed_batch_wait(ed_batch* batch, void* stream);
+
 /* device-resident results of the last ed_batch_run */
 const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples] */
 const uint8_t* ed_batch_path(const ed_batch* batch);   /* [n_exons][n_samples]    */
@@ -239,6 +252,10 @@ int ed_batch_verify_emissions(ed_batch* batch, const int32_t* d_test, const int3
  *       3 call table (scan + fill), 4 dispersion fit.  Synchronises. */
 int ed_batch_enable_timing(ed_batch* batch, int enable);
 int ed_batch_stage_ms(ed_batch* batch, float ms[5]);
+/* The same stage times summed over every timed ed_batch_run (n_runs) and fit (n_fits) since timing was enabled: what a
+ * pipelined caller reads once at the end instead of synchronising after every batch (the library folds the events of a
+ * batch's previous run into the sums when the next run on that batch is issued). */
+int ed_batch_stage_ms_total(ed_batch* batch, double ms_total[5], int64_t* n_runs, int64_t* n_fits);
 
 /* =====================================================================================
  * 3. Reference-set optimisation (the "next" row of the path: select.reference.set)

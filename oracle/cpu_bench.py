@@ -1,34 +1,54 @@
-"""TEST INFRASTRUCTURE: per-sample CPU work unit for bench.py's `cpu_baseline` leg (process-level sample
-parallelism over the host cores; the reference itself is single-threaded, vignette/vignette.Rnw:390-431 loops over
-samples).  Only bench.py's cpu_baseline leg imports this."""
+"""TEST INFRASTRUCTURE: all-core leg of bench.py's `cpu_baseline` (process-level sample parallelism over the host cores;
+the reference itself is single-threaded, vignette/vignette.Rnw:390-431 loops over samples).  Only bench.py imports this.
+
+One worker process per core, pinned to it (sched_setaffinity); every worker loads the checker, waits at a barrier, then
+times ITS OWN loop over the samples it was dealt -- process start-up, pickling and library loading are outside the
+timed region.  Rate = cells of all workers / the slowest worker's time."""
+import os
 import time
 
 import numpy as np
 
 
-def one_sample(args):
-    """emissions + Viterbi + call table (+ Nelder-Mead stand-in fit) for one sample column; returns seconds."""
-    test, ref, phi, p, chrom_off, start, end, fit = args
+def _worker(core, barrier, queue, cols, chrom_off, start, end, fit):
+    try:
+        os.sched_setaffinity(0, {core})
+    except (AttributeError, OSError):
+        pass
     from oracle import edoracle as eo
+    eo.lib()
+    barrier.wait()
     t0 = time.perf_counter()
-    if fit:
-        eo.fit_nm(test, ref)
-    ll, _ = eo.get_loglike_matrix(phi, p, test + ref, test, 1.0, eo.LIBM)
-    eo.callcnvs(ll, chrom_off, start, end)
-    return time.perf_counter() - t0
+    for test, ref, phi, p in cols:
+        if fit:
+            eo.fit_nm(test, ref)
+        ll, _ = eo.get_loglike_matrix(phi, p, test + ref, test, 1.0, eo.LIBM)
+        eo.callcnvs(ll, chrom_off, start, end)
+    queue.put((core, time.perf_counter() - t0, len(cols)))
 
 
-def all_cores(test_h, ref_h, p, phi, chrom_off, start, end, fit, cores):
-    """Run `cores` samples (one per process) concurrently; returns (cells per second, wall seconds, processes)."""
-    import concurrent.futures as cf
+def all_cores(test_h, ref_h, p, phi, chrom_off, start, end, fit, max_workers):
     import multiprocessing as mp
 
-    n = min(cores, test_h.shape[1])
-    jobs = [(np.ascontiguousarray(test_h[:, s]), np.ascontiguousarray(ref_h[:, s]), float(phi[s]), float(p[s]),
-             chrom_off, start, end, bool(fit)) for s in range(n)]
-    with cf.ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn")) as ex:
-        list(ex.map(one_sample, jobs[:n]))          # start the workers, load the library (untimed)
-        t0 = time.perf_counter()
-        list(ex.map(one_sample, jobs))
-        wall = time.perf_counter() - t0
-    return test_h.shape[0] * n / wall, wall, n
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = cores[:max_workers]
+    n_s = test_h.shape[1]
+    ctx = mp.get_context("spawn")
+    barrier = ctx.Barrier(len(cores))
+    queue = ctx.Queue()
+    procs = []
+    for i, core in enumerate(cores):
+        s = i % n_s      # one sample per worker (same work per worker; samples are reused when there are more cores)
+        cols = [(np.ascontiguousarray(test_h[:, s]), np.ascontiguousarray(ref_h[:, s]), float(phi[s]), float(p[s]))]
+        pr = ctx.Process(target=_worker, args=(core, barrier, queue, cols, chrom_off, start, end, bool(fit)))
+        pr.start()
+        procs.append(pr)
+    res = [queue.get() for _ in procs]
+    for pr in procs:
+        pr.join()
+    slowest = max(r[1] for r in res)
+    n_done = sum(r[2] for r in res)
+    return {"value": test_h.shape[0] * n_done / slowest, "unit": "exons*samples/s", "cores": len(cores),
+            "slowest_worker_s": slowest, "mean_worker_s": float(np.mean([r[1] for r in res])),
+            "sample": "%d workers pinned one per logical core, one sample column of %d exons each, timed inside the workers "
+                      "after a common barrier" % (len(cores), test_h.shape[0])}

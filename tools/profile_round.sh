@@ -21,9 +21,18 @@ with open(out + "/kernel_stats.csv", "w", newline="") as f:
 PY
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   N=$(echo $C | cut -d' ' -f1)
+  [ "$N" = "SQ_WAVES" ] && N=SQ
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o pmc_$N -- python bench.py --steps 2 --warmup 1 --cpu-samples 0 > $OUT/pmc_$N.log 2>&1
   python tools/pmc_summary.py $OUT/pmc_${N}_counter_collection.csv > $OUT/pmc_$N.csv
   rm -f $OUT/pmc_${N}_counter_collection.csv $OUT/pmc_${N}_kernel_trace.csv
 done
+python - "$OUT" "$TAG" <<'PY'
+import json, sys, time
+sys.path.insert(0, ".")
+from exomedepth_amd import _build
+json.dump({"tag": sys.argv[2], "csrc_sha16": _build.csrc_sha16(), "pmc_steps": 3, "kernel_stats_steps": 6,
+           "taken": time.strftime("%Y-%m-%d %H:%M:%S"), "bench_args": "--steps 2 --warmup 1 (PMC passes); --steps 5 --warmup 1 (kernel trace)"},
+          open(sys.argv[1] + "/meta.json", "w"), indent=1)
+PY
 rm -f $OUT/ks_kernel_trace.csv $OUT/ks_domain_stats.csv $OUT/*agent_info.csv
 ls -la $OUT
