@@ -313,4 +313,36 @@ ED_PM_FN double ed_psin_0pi(double t)
   return ed_pm_fma(t * w, p, t);
 }
 
+/* sine of any finite t with |t| < 2^52: t = k pi + r through a three-part pi (each step one fma; the first two are exact
+ * for the k that occur), then the polynomial above on |r| <= pi/2.  Absolute error ~2e-16.  Used by the cold path of
+ * log|Gamma(x)| for negative x (sign of sin(pi x), its magnitude where it is at least 0.015 pi). */
+#define ED_PM_INV_PI 0x1.45f306dc9c883p-2
+#define ED_PM_PI_LO2 -0x1.f1976b7ed8fbcp-109
+ED_PM_FN double ed_psin_any(double t)
+{
+  if (!(t > -0x1p52 && t < 0x1p52)) return ed_pm_nan();
+  const double k = (t * ED_PM_INV_PI + 0x1.8p52) - 0x1.8p52;      /* nearest integer */
+  double r = ed_pm_fma(-k, ED_PM_PI_HI, t);
+  r = ed_pm_fma(-k, ED_PM_PI_LO, r);
+  r = ed_pm_fma(-k, ED_PM_PI_LO2, r);
+  const double a = ed_psin_0pi(r < 0.0 ? -r : r);
+  const int odd = (int)(((int64_t)k) & 1);
+  return ((r < 0.0) != (odd != 0)) ? -a : a;
+}
+
+/* b^-n for a small positive integer n (3..7 on the path) and b >= 3: repeated multiplication, one division */
+ED_PM_FN double ed_ppown(double b, int n)
+{
+  double p = b;
+  for (int i = 1; i < n; ++i) p *= b;
+  return 1.0 / p;
+}
+
+/* B_2j / (2j)!, j = 0..14 (Euler-Maclaurin coefficients of the Hurwitz zeta function; reference src/VP_zeta.c:563-579) */
+#define ED_HZETA_C { 1.00000000000000000000000000000, 0.083333333333333333333333333333, -0.00138888888888888888888888888889, \
+  0.000033068783068783068783068783069, -8.2671957671957671957671957672e-07, 2.0876756987868098979210090321e-08, \
+  -5.2841901386874931848476822022e-10, 1.3382536530684678832826980975e-11, -3.3896802963225828668301953912e-13, \
+  8.5860620562778445641359054504e-15, -2.1748686985580618730415164239e-16, 5.5090028283602295152026526089e-18, \
+  -1.3954464685812523340707686264e-19, 3.5347070396294674716932299778e-21, -8.9535174270375468504026113181e-23 }
+
 #endif /* ED_PMATH_H */

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ed_pmath.h"
+#include "ed_sing_tables.h"
 
 // Cold functions (ranges the path rarely or never reaches) are kept out of line so that the hot routes stay small.
 // -DED_COLD_INLINE builds the diagnostic variant of the library in which they are inlined instead
@@ -70,6 +71,13 @@ __constant__ const double k_lopx[21] = {
     1.4844576692270934446023686322e-11,  -2.0328515972462118942821556033e-12, 2.7291231220549214896095654769e-13,
     -3.7581977830387938294437434651e-14, 5.1107345870861673561462339876e-15,  -7.0722150011433276578323272272e-16,
     9.7089758328248469219003866867e-17,  -1.3492637457521938883731579510e-17, 1.8657327910677296608121390705e-18};
+
+// n!, psi(n), psi'(n) (tools/gen_sing_tables.py) and B_2j/(2j)! (src/VP_zeta.c:563-579): only log|Gamma| next to a negative
+// integer reads them (lngamma_sgn_sing below)
+__constant__ const double k_fact[ED_FACT_TABLE_N] = ED_FACT_TABLE;
+__constant__ const double k_psi_int[ED_PSI_TABLE_N] = ED_PSI_TABLE;
+__constant__ const double k_psi1_int[ED_PSI1_TABLE_N] = ED_PSI1_TABLE;
+__constant__ const double k_hzeta_c[15] = ED_HZETA_C;
 
 // ---- correctly rounded division without the scaling / fix-up stages ----------------------------
 // a/b as hipcc lowers it is  v_div_scale x2, v_rcp, 2 Newton steps, multiply, residual, v_div_fmas,
@@ -270,89 +278,194 @@ __device__ __forceinline__ double log1plusx_ratio(double x)
   return x * clenshaw<20>(k_lopx, t);
 }
 
-// Everything lnbeta can be asked outside x>0, y>0 (zero, negative, NaN arguments).  Value semantics
-// of the reference's natural-prototype wrapper (src/beta.c:161-164, src/eval.h:3-9):
-//   x==0 or y==0                 -> NaN  (domain error, src/beta.c:54-56)
-//   NaN argument                 -> its log-Gamma term is 0.0 (the comparisons of src/VP_gamma.c:1221-1277
-//                                   all fail and the EROUND exit :1278-1283 returns 0), so e.g.
-//                                   lnbeta(NaN,NaN) = 0.0 and lnbeta(NaN,5) = lgamma(5)
-//   negative argument            -> NaN.  DEVIATION for non-integer negatives: the reference evaluates the
-//                                   reflection formula; a negative shape parameter needs phi > 1, which is
-//                                   outside the model's domain (negative integers are NaN in the reference too).
-// *flag is set to 1: in all these cases the reference raises a GSL error (two printed lines per event).
-__device__ EDSF_COLD double lnbeta_cold(double x, double y, int* flag)
+// ---- log|Gamma(x)| with sign for ANY x, as gsl_sf_lngamma_sgn_e computes it (src/VP_gamma.c:1219-1285) -- the cold
+// side of the path: a non-positive or NaN shape parameter needs phi >= 1 or expected outside (0, 1).  Operation for
+// operation the portable flavour of the checker (oracle/edo_gsl.inc), whose libm flavour is bit-identical to the
+// reference build on these arguments (tests/test_oracle_ref.py).
+
+// gsl_sf_lnfact_e (src/VP_gamma.c:1548-1561)
+__device__ __forceinline__ double lnfact_u(unsigned n)
 {
-  *flag = 1;
-  if (x == 0.0 || y == 0.0) return ed_pm_nan();
-  if (x < 0.0 || y < 0.0) return ed_pm_nan();
-  const double xy = x + y;
-  const double lgx = (x != x) ? 0.0 : lngamma_pos(x, false);
-  const double lgy = (y != y) ? 0.0 : lngamma_pos(y, false);
-  const double lgxy = (xy != xy) ? 0.0 : lngamma_pos(xy, false);
-  return (lgx + lgy) - lgxy;
+  if (n <= 170u) return ed_plog(k_fact[n]);
+  double x = (double)n + 1.0;          // gsl_sf_lngamma_e(n + 1.0) -> Lanczos; plain divisions as in the checker
+  x -= 1.0;
+  double Ag = 0.99999999999980993227684700473478;
+  Ag += 676.520368121885098567009190444019 / (x + 1.0);
+  Ag += -1259.13921672240287047156078755283 / (x + 2.0);
+  Ag += 771.3234287776530788486528258894 / (x + 3.0);
+  Ag += -176.61502916214059906584551354 / (x + 4.0);
+  Ag += 12.507343278686904814458936853 / (x + 5.0);
+  Ag += -0.13857109526572011689554707 / (x + 6.0);
+  Ag += 9.984369578019570859563e-6 / (x + 7.0);
+  Ag += 1.50563273514931155834e-7 / (x + 8.0);
+  const double term1 = (x + 0.5) * ed_plog((x + 7.5) / EDSF_M_E);
+  const double term2 = EDSF_LOGROOT2PI + ed_plog(Ag);
+  return term1 + (term2 - 7.0);
 }
 
-// Which gsl_error() calls the reference makes while it evaluates gsl_sf_lnbeta(x, y) -- the text it prints through
-// Rprintf (src/error.c:45-48) is a function of these.  Bits of the result:
-//   0-2, 3-5, 6-8  the error raised inside gsl_sf_lngamma_sgn_e for x, y, x+y (general route, src/beta.c:104-106):
-//                  0 none, 1 VP_gamma.c:1283 (EROUND: NaN or |x| too large), 2 :1239 (x == 0), 3 :1253 (sin(pi x) == 0),
-//                  4 :803 (exactly a negative integer inside lngamma_sgn_sing), 5 :1261 (x < INT_MIN + 2)
-//   9   beta.c:56 (x == 0 or y == 0)     10  beta.c:59 (a negative integer argument)     11  beta.c:44 (B(x,y) < 0)
-// Any bit set => the natural-prototype wrapper adds beta.c:163 (src/eval.h:3-9).  Zero: no error.
-// Sign and branch selection follow src/VP_gamma.c:1219-1285 and :795-894 (the sign of lngamma_sgn_sing).
-enum : unsigned { kSiteB56 = 1u << 9, kSiteB59 = 1u << 10, kSiteB44 = 1u << 11 };
-
-// sin(t) for any finite t with |t| < 2^52 (absolute error ~2e-16): t = k pi + r with a three-part pi, then the
-// polynomial of ed_psin_0pi on |r| <= pi/2.  Only signs and the |s| < 0.015 pi test of the cold path depend on it.
-__device__ __forceinline__ double psin_any(double t)
+// gsl_sf_psi_int_e / gsl_sf_psi_1_int_e (src/VP_psi.c:604-630, :717-741), n >= 1
+__device__ __forceinline__ double psi_int(int n)
 {
-  const double k = __builtin_rint(t * 0.31830988618379067154);
-  double r = __builtin_fma(-k, 0x1.921fb54442d18p+1, t);
-  r = __builtin_fma(-k, 0x1.1a62633145c07p-53, r);
-  r = __builtin_fma(-k, -0x1.f1976b7ed8fbcp-109, r);
-  const double a = ed_psin_0pi(fabs(r));
-  const bool odd = (((long long)k) & 1ll) != 0;
-  return ((r < 0.0) != odd) ? -a : a;
+  if (n <= 100) return k_psi_int[n];
+  const double c2 = -1.0 / 12.0, c3 = 1.0 / 120.0, c4 = -1.0 / 252.0, c5 = 1.0 / 240.0;
+  const double ni2 = (1.0 / n) * (1.0 / n);
+  const double ser = ni2 * (c2 + ni2 * (c3 + ni2 * (c4 + ni2 * c5)));
+  return (ed_plog((double)n) - 0.5 / n) + ser;
+}
+__device__ __forceinline__ double psi_1_int(int n)
+{
+  if (n <= 100) return k_psi1_int[n];
+  const double c0 = -1.0 / 30.0, c1 = 1.0 / 42.0, c2 = -1.0 / 30.0;
+  const double ni2 = (1.0 / n) * (1.0 / n);
+  const double ser = (ni2 * ni2) * (c0 + ni2 * (c1 + c2 * ni2));
+  return (((1.0 + 0.5 / n) + 1.0 / ((6.0 * n) * n)) + ser) / n;
 }
 
-__device__ __forceinline__ unsigned lngamma_site(double x, double* sgn)
+// gsl_sf_hzeta_e(s, q), Euler-Maclaurin branch (src/VP_zeta.c:775-803), s = 3..7, q >= 3
+__device__ __noinline__ double hzeta_int(int si, double q)
 {
-  if (fabs(x - 1.0) < 0.01 || fabs(x - 2.0) < 0.01 || x >= 0.5) { *sgn = 1.0; return 0u; }
-  if (x == 0.0) { *sgn = 0.0; return 2u; }
-  if (fabs(x) < 0.02) { *sgn = (x >= 0.0) ? 1.0 : -1.0; return 0u; }
+  const double s = (double)si;
+  const int jmax = 12, kmax = 10;
+  const double pmax = ed_ppown(kmax + q, si);
+  double scp = s;
+  double pcp = pmax / (kmax + q);
+  double ans = pmax * ((kmax + q) / (s - 1.0) + 0.5);
+  for (int k = 0; k < kmax; k++) ans += ed_ppown(k + q, si);
+  for (int j = 0; j <= jmax; j++) {
+    const double delta = (k_hzeta_c[j + 1] * scp) * pcp;
+    ans += delta;
+    if (fabs(delta / ans) < 0.5 * EDSF_DBL_EPS) break;
+    scp *= ((s + 2 * j) + 1) * ((s + 2 * j) + 2);
+    pcp /= (kmax + q) * (kmax + q);
+  }
+  return ans;
+}
+
+// gsl_sf_psi_n_e for n >= 2 (src/VP_psi.c:790-821)
+__device__ __forceinline__ double psi_n(int n, double x)
+{
+  const double v = hzeta_int(n + 1, x) * ed_pexp(lnfact_u((unsigned)n));
+  return (n % 2 == 0) ? -v : v;
+}
+
+// lngamma_sgn_sing (src/VP_gamma.c:795-894): x = -N + eps.  Returns the value; *site = 4 on eps == 0 (:803).
+__device__ __noinline__ double lngamma_sgn_sing(int N, double eps, double* sgn, unsigned* site)
+{
+  if (eps == 0.0) { *sgn = 0.0; *site = 4u; return 0.0; }
+  if (N == 1) {
+    const double c0 = 0.07721566490153286061, c1 = 0.08815966957356030521, c2 = -0.00436125434555340577,
+                 c3 = 0.01391065882004640689, c4 = -0.00409427227680839100, c5 = 0.00275661310191541584,
+                 c6 = -0.00124162645565305019, c7 = 0.00065267976121802783, c8 = -0.00032205261682710437,
+                 c9 = 0.00016229131039545456;
+    const double g5 = c5 + eps * (c6 + eps * (c7 + eps * (c8 + eps * c9)));
+    const double g = eps * (c0 + eps * (c1 + eps * (c2 + eps * (c3 + eps * (c4 + eps * g5)))));
+    const double gam_e = (g - 1.0) - ((0.5 * eps) * (1.0 + 3.0 * eps)) / (1.0 - eps * eps);
+    *sgn = (eps > 0.0 ? -1.0 : 1.0);
+    return ed_plog(fabs(gam_e) / fabs(eps));
+  }
+  const double cs1 = -1.6449340668482264365, cs2 = 0.8117424252833536436, cs3 = -0.1907518241220842137,
+               cs4 = 0.0261478478176548005, cs5 = -0.0023460810354558236;
+  const double e2 = eps * eps;
+  const double sin_ser = 1.0 + e2 * (cs1 + e2 * (cs2 + e2 * (cs3 + e2 * (cs4 + e2 * cs5))));
+  const double aeps = fabs(eps);
+  double psi_2 = 0.0, psi_3 = 0.0, psi_4 = 0.0, psi_5 = 0.0, psi_6 = 0.0;
+  const double c0 = lnfact_u((unsigned)N);
+  const double psi_0 = psi_int(N + 1);
+  const double psi_1 = psi_1_int(N + 1);
+  if (aeps > 0.00001) psi_2 = psi_n(2, N + 1.0);
+  if (aeps > 0.0002) psi_3 = psi_n(3, N + 1.0);
+  if (aeps > 0.001) psi_4 = psi_n(4, N + 1.0);
+  if (aeps > 0.005) psi_5 = psi_n(5, N + 1.0);
+  if (aeps > 0.01) psi_6 = psi_n(6, N + 1.0);
+  const double c1 = psi_0, c2 = psi_1 / 2.0, c3 = psi_2 / 6.0, c4 = psi_3 / 24.0, c5 = psi_4 / 120.0, c6 = psi_5 / 720.0,
+               c7 = psi_6 / 5040.0;
+  const double lng_ser = c0 - eps * (c1 - eps * (c2 - eps * (c3 - eps * (c4 - eps * (c5 - eps * (c6 - eps * c7))))));
+  const double g = -lng_ser - ed_plog(sin_ser);
+  *sgn = ((N & 1) ? -1.0 : 1.0) * (eps > 0.0 ? 1.0 : -1.0);
+  return g - ed_plog(fabs(eps));
+}
+
+// gsl_sf_lngamma_sgn_e (src/VP_gamma.c:1219-1285).  *site: the gsl_error() call the reference makes (0 none,
+// 1 VP_gamma.c:1283, 2 :1239, 3 :1253, 4 :803, 5 :1261); values on those sites as the reference leaves them.
+__device__ __noinline__ double lngamma_sgn_any(double x, double* sgn, unsigned* site)
+{
+  *site = 0u;
+  *sgn = 1.0;
+  if (fabs(x - 1.0) < 0.01) return lngamma_pade(x - 1.0, 0);
+  if (fabs(x - 2.0) < 0.01) return lngamma_pade(x - 2.0, 1);
+  if (x >= 0.5) return lngamma_lanczos(x);
+  if (x == 0.0) { *sgn = 0.0; *site = 2u; return ed_pm_nan(); }
+  if (fabs(x) < 0.02) {                                     // lngamma_sgn_0 (:761-787), either sign of x
+    *sgn = (x >= 0.0) ? 1.0 : -1.0;
+    if (x > 0.0) return lngamma_below_half(x, false);
+    const double c1 = -0.07721566490153286061, c2 = -0.01094400467202744461, c3 = 0.09252092391911371098,
+                 c4 = -0.01827191316559981266, c5 = 0.01800493109685479790, c6 = -0.00685088537872380685,
+                 c7 = 0.00399823955756846603, c8 = -0.00189430621687107802, c9 = 0.00097473237804513221,
+                 c10 = -0.00048434392722255893;
+    const double g6 = c6 + x * (c7 + x * (c8 + x * (c9 + x * c10)));
+    const double g = x * (c1 + x * (c2 + x * (c3 + x * (c4 + x * (c5 + x * g6)))));
+    const double gee = (g + 1.0 / (1.0 + x)) + 0.5 * x;
+    return ed_plog(gee / fabs(x));
+  }
   if (x > -0.5 / (EDSF_DBL_EPS * EDSF_M_PI)) {
-    const double s = psin_any(EDSF_M_PI * x);
-    if (s == 0.0) { *sgn = 0.0; return 3u; }
-    if (fabs(s) < EDSF_M_PI * 0.015) {
-      if (x < -2147483648.0 + 2.0) { *sgn = 0.0; return 5u; }
+    if (x > 0.0) return lngamma_below_half(x, false);      // 0.02 <= x < 0.5: |sin(pi x)| > 0.015 pi, sign +
+    const double z = 1.0 - x;
+    const double s = ed_psin_any(EDSF_M_PI * x);
+    const double as = fabs(s);
+    if (s == 0.0) { *sgn = 0.0; *site = 3u; return ed_pm_nan(); }
+    if (as < EDSF_M_PI * 0.015) {
+      if (x < -2147483648.0 + 2.0) { *sgn = 0.0; *site = 5u; return 0.0; }
       const int N = -(int)(x - 0.5);
       const double eps = x + N;
-      if (eps == 0.0) { *sgn = 0.0; return 4u; }
-      if (N == 1) *sgn = (eps > 0.0) ? -1.0 : 1.0;
-      else *sgn = ((N & 1) ? -1.0 : 1.0) * ((eps > 0.0) ? 1.0 : -1.0);
-      return 0u;
+      return lngamma_sgn_sing(N, eps, sgn, site);
     }
-    *sgn = (s > 0.0) ? 1.0 : -1.0;
-    return 0u;
+    *sgn = (s > 0.0 ? 1.0 : -1.0);
+    return EDSF_M_LNPI - (ed_plog(as) + lngamma_lanczos(z));
   }
-  *sgn = 0.0;
-  return 1u;
+  *sgn = 0.0; *site = 1u;                                   // |x| too large, or NaN (:1278-1283)
+  return 0.0;
 }
 
-__device__ __noinline__ unsigned lnbeta_sites(double x, double y)
+// Everything lnbeta can be asked outside x > 0, y > 0 (zero, negative, NaN arguments): value semantics of the reference's
+// natural-prototype wrapper (src/beta.c:161-164, src/eval.h:3-9) over gsl_sf_lnbeta_e (:38-47) and gsl_sf_lnbeta_sgn_e
+// (:49-114, general route :101-112):
+//   x == 0 or y == 0, or a negative integer      -> NaN (domain error :56 / :59)
+//   otherwise lgamma(x) + lgamma(y) - lgamma(x + y) through gsl_sf_lngamma_sgn_e; a NaN argument contributes 0.0 (its
+//   comparisons all fail and the EROUND exit returns 0), so lnbeta(NaN, NaN) = 0.0;  B(x, y) < 0 -> NaN (:43-45)
+// *sites: which gsl_error() calls the reference makes -- what it prints through Rprintf (src/error.c:45-48):
+//   bits 0-2, 3-5, 6-8  the site inside gsl_sf_lngamma_sgn_e for x, y, x+y (codes of lngamma_sgn_any)
+//   9   beta.c:56     10  beta.c:59     11  beta.c:44
+// Any bit set => the wrapper adds beta.c:163 and the call counts as one GSL error event.
+enum : unsigned { kSiteB56 = 1u << 9, kSiteB59 = 1u << 10, kSiteB44 = 1u << 11 };
+__device__ EDSF_COLD double lnbeta_cold_sites(double x, double y, unsigned* sites)
 {
-  if (x == 0.0 || y == 0.0) return kSiteB56;
-  if ((x < 0.0 && x == __builtin_floor(x)) || (y < 0.0 && y == __builtin_floor(y))) return kSiteB59;
-  if (x > 0.0 && y > 0.0) {
-    const double mx = (x > y ? x : y), mn = (x < y ? x : y);
-    if (mn / mx < 0.2) return 0u;
-  }
+  if (x == 0.0 || y == 0.0) { *sites = kSiteB56; return ed_pm_nan(); }
+  if ((x < 0.0 && x == __builtin_floor(x)) || (y < 0.0 && y == __builtin_floor(y))) { *sites = kSiteB59; return ed_pm_nan(); }
   double sx, sy, sxy;
-  unsigned code = lngamma_site(x, &sx);
-  code |= lngamma_site(y, &sy) << 3;
-  code |= lngamma_site(x + y, &sxy) << 6;
-  if (sx * sy * sxy == -1.0) code |= kSiteB44;
-  return code;
+  unsigned e1, e2, e3;
+  const double lgx = lngamma_sgn_any(x, &sx, &e1);
+  const double lgy = lngamma_sgn_any(y, &sy, &e2);
+  const double lgxy = lngamma_sgn_any(x + y, &sxy, &e3);
+  unsigned code = e1 | (e2 << 3) | (e3 << 6);
+  double v = (lgx + lgy) - lgxy;
+  if ((sx * sy) * sxy == -1.0) { code |= kSiteB44; v = ed_pm_nan(); }
+  *sites = code;
+  return v;
+}
+__device__ __forceinline__ double lnbeta_cold(double x, double y, int* flag)
+{
+  unsigned sites;
+  const double v = lnbeta_cold_sites(x, y, &sites);
+  *flag = sites ? 1 : 0;
+  return v;
+}
+// the sites alone, for any (x, y)
+__device__ __forceinline__ unsigned lnbeta_sites(double x, double y)
+{
+  if (x > 0.0 && y > 0.0) return 0u;     // both routes of the positive quadrant are error-free
+  unsigned sites;
+  (void)lnbeta_cold_sites(x, y, &sites);
+  return sites;
 }
 
 // The two value-exact evaluation routes of log B for x,y > 0 (src/beta.c:62-113), split so that a

@@ -1406,6 +1406,10 @@ __global__ void k_eval_sf(int which, int64_t n, const double* __restrict__ x, co
     case 8: r = edsf::fdiv(x[i], y[i]); break;
     case 9: r = edsf::pexp_small(x[i]); break;
     case 10: r = edsf::plog_fast(x[i]); break;
+    case 11: r = (double)edsf::lnbeta_sites(x[i], y[i]); break;
+    case 12: { double sg; unsigned st; r = edsf::lngamma_sgn_any(x[i], &sg, &st); } break;
+    case 13: { double sg; unsigned st; (void)edsf::lngamma_sgn_any(x[i], &sg, &st); r = sg + 8.0 * (double)st; } break;
+    case 14: r = ed_psin_any(x[i]); break;
     default: r = ed_pm_nan();
   }
   out[i] = r;

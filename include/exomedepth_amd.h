@@ -321,7 +321,9 @@ int ed_synchronize(void* stream);
 /* Element-wise evaluation of the device special functions on host arrays (used by the parity tests
  * to compare the device arithmetic with the checker bit for bit).
  * which: 0 lnbeta(x,y)  1 portable log(x)  2 portable exp(x)  3 sqrt(x)  4 x/y  5 portable sin(x) on [0,pi]
- *        6 digamma(x)  7 trigamma(x)  8 in-range exact division x/y  9 exp for |x| < ln2/2  10 log, fast path */
+ *        6 digamma(x)  7 trigamma(x)  8 in-range exact division x/y  9 exp for |x| < ln2/2  10 log, fast path
+ *        11 error sites of lnbeta(x,y) (see ed_get_loglike_matrix_messages)  12 log|Gamma(x)| for any x
+ *        13 sign of Gamma(x) + 8 * its error site  14 portable sin(x), |x| < 2^52 */
 int ed_eval_sf(int which, int64_t n, const double* x, const double* y, double* out);
 
 #ifdef __cplusplus

@@ -25,11 +25,11 @@
 #include <time.h>
 
 #include "../exomedepth_amd/csrc/ed_pmath.h"
+#include "../exomedepth_amd/csrc/ed_sing_tables.h"
 
 #define EDO_SUCCESS 0
 #define EDO_EDOM 1      /* GSL_EDOM   */
 #define EDO_EROUND 18   /* GSL_EROUND */
-#define EDO_EUNSUP 1000 /* branch deliberately not restated (see edo_gsl.inc) */
 
 /* constants as spelled in reference src/gsl_math.h and src/gsl_machine.h */
 #define EDO_M_E 2.71828182845904523536028747135
@@ -80,17 +80,30 @@ static const double edo_lanczos_7_c[9] = {
   771.3234287776530788486528258894, -176.61502916214059906584551354, 12.507343278686904814458936853,
   -0.13857109526572011689554707, 9.984369578019570859563e-6, 1.50563273514931155834e-7};
 
+/* n!, psi(n), psi'(n): mathematical constants generated by tools/gen_sing_tables.py (bitwise the reference's tables), and
+ * the Euler-Maclaurin coefficients B_2j / (2j)! of src/VP_zeta.c:563-579 */
+static const double edo_fact_table[ED_FACT_TABLE_N] = ED_FACT_TABLE;
+static const double edo_psi_table[ED_PSI_TABLE_N] = ED_PSI_TABLE;
+static const double edo_psi1_table[ED_PSI1_TABLE_N] = ED_PSI1_TABLE;
+static const double edo_hzeta_c[15] = ED_HZETA_C;
+static double edo_pown_libm(double b, int n) { return pow(b, -(double)n); }
+static double edo_pown_port(double b, int n) { return ed_ppown(b, n); }
+
 /* ---- flavour 1: libm transcendental functions (what the reference itself calls) ---- */
 #define F(name) edo_libm_##name
 #define EDO_LOG log
 #define EDO_EXP exp
 #define EDO_SIN sin
+#define EDO_SIN_ANY sin
+#define EDO_POWN edo_pown_libm
 #define EDO_PORTABLE 0
 #include "edo_gsl.inc"
 #undef F
 #undef EDO_LOG
 #undef EDO_EXP
 #undef EDO_SIN
+#undef EDO_SIN_ANY
+#undef EDO_POWN
 #undef EDO_PORTABLE
 
 /* ---- flavour 2: portable transcendental functions (bit-exact target of the HIP kernels) ---- */
@@ -98,12 +111,16 @@ static const double edo_lanczos_7_c[9] = {
 #define EDO_LOG ed_plog
 #define EDO_EXP ed_pexp
 #define EDO_SIN ed_psin_0pi
+#define EDO_SIN_ANY ed_psin_any
+#define EDO_POWN edo_pown_port
 #define EDO_PORTABLE 1
 #include "edo_gsl.inc"
 #undef F
 #undef EDO_LOG
 #undef EDO_EXP
 #undef EDO_SIN
+#undef EDO_SIN_ANY
+#undef EDO_POWN
 #undef EDO_PORTABLE
 
 /* =====================================================================================
@@ -114,6 +131,7 @@ static const double edo_lanczos_7_c[9] = {
 EDO_API void edo_plog_v(long n, const double *x, double *out) { for (long i = 0; i < n; i++) out[i] = ed_plog(x[i]); }
 EDO_API void edo_pexp_v(long n, const double *x, double *out) { for (long i = 0; i < n; i++) out[i] = ed_pexp(x[i]); }
 EDO_API void edo_psin_v(long n, const double *x, double *out) { for (long i = 0; i < n; i++) out[i] = ed_psin_0pi(x[i]); }
+EDO_API void edo_psin_any_v(long n, const double *x, double *out) { for (long i = 0; i < n; i++) out[i] = ed_psin_any(x[i]); }
 
 EDO_API long edo_lnbeta_v(int flavour, long n, const double *x, const double *y, double *out)
 {
@@ -308,6 +326,39 @@ EDO_API int edo_ref_call2(const char *name, long n, const double *x, const doubl
   if (!fn) return -2;
   for (long i = 0; i < n; i++) out[i] = fn(x[i], y[i]);
   return 0;
+}
+
+/* gsl_sf_lngamma_sgn_e(x, &result, &sgn) of the reference build (error-free arguments only: see above) */
+EDO_API int edo_ref_lngamma_sgn(long n, const double *x, double *val, double *sgn, int *status)
+{
+  if (!edo_ref_handle) return -1;
+  struct res { double val, err; };
+  int (*fn)(double, struct res *, double *) = (int (*)(double, struct res *, double *))dlsym(edo_ref_handle, "gsl_sf_lngamma_sgn_e");
+  if (!fn) return -2;
+  for (long i = 0; i < n; i++) {
+    struct res r = {0, 0};
+    double sg = 0;
+    status[i] = fn(x[i], &r, &sg);
+    val[i] = r.val; sgn[i] = sg;
+  }
+  return 0;
+}
+
+/* the checker's gsl_sf_lngamma_sgn_e: value, sign, status */
+EDO_API void edo_lngamma_sgn_v(int flavour, long n, const double *x, double *val, double *sgn, int *status)
+{
+  for (long i = 0; i < n; i++)
+    status[i] = flavour ? edo_port_lngamma_sgn(x[i], 0, &val[i], &sgn[i]) : edo_libm_lngamma_sgn(x[i], 0, &val[i], &sgn[i]);
+}
+
+/* gsl_sf_lnbeta with the error sites (codes of edsf::lnbeta_sites) */
+EDO_API void edo_lnbeta_sites_v(int flavour, long n, const double *x, const double *y, double *val, int *sites)
+{
+  for (long i = 0; i < n; i++) {
+    unsigned c = 0;
+    if (flavour) edo_port_lnbeta_e_sites(x[i], y[i], &val[i], &c); else edo_libm_lnbeta_e_sites(x[i], y[i], &val[i], &c);
+    sites[i] = (int)c;
+  }
 }
 
 /* monotonic seconds, for bench.py's cpu_baseline leg */

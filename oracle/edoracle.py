@@ -34,7 +34,7 @@ def lib():
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
-        for name in ("edo_plog_v", "edo_pexp_v", "edo_psin_v"):
+        for name in ("edo_plog_v", "edo_pexp_v", "edo_psin_v", "edo_psin_any_v"):
             getattr(L, name).argtypes = [C.c_long, _dp, _dp]
             getattr(L, name).restype = None
         L.edo_lnbeta_v.argtypes = [C.c_int, C.c_long, _dp, _dp, _dp]
@@ -54,6 +54,12 @@ def lib():
         L.edo_ref_call2.argtypes = [C.c_char_p, C.c_long, _dp, _dp, _dp]
         L.edo_ref_call2.restype = C.c_int
         L.edo_now.restype = C.c_double
+        L.edo_ref_lngamma_sgn.argtypes = [C.c_long, _dp, _dp, _dp, _ip]
+        L.edo_ref_lngamma_sgn.restype = C.c_int
+        L.edo_lngamma_sgn_v.argtypes = [C.c_int, C.c_long, _dp, _dp, _dp, _ip]
+        L.edo_lngamma_sgn_v.restype = None
+        L.edo_lnbeta_sites_v.argtypes = [C.c_int, C.c_long, _dp, _dp, _dp, _ip]
+        L.edo_lnbeta_sites_v.restype = None
         L.edo_psi_v.argtypes = [C.c_long, _dp, _dp, _dp]
         L.edo_psi_v.restype = None
         L.edo_fit_mle.argtypes = [_ip, _ip, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -90,6 +96,10 @@ def psin(x):
     x = _f64(x); out = np.empty_like(x); lib().edo_psin_v(x.size, x, out); return out
 
 
+def psin_any(x):
+    x = _f64(x); out = np.empty_like(x); lib().edo_psin_any_v(x.size, x, out); return out
+
+
 def lnbeta(x, y, flavour=PORTABLE):
     x = _f64(x); y = _f64(y); out = np.empty_like(x)
     lib().edo_lnbeta_v(flavour, x.size, x, y, out)
@@ -103,6 +113,29 @@ def sf(which, x, flavour=PORTABLE):
     x = _f64(x); out = np.empty_like(x); st = np.zeros(x.size, dtype=np.int32)
     lib().edo_sf_v(flavour, _SF[which], x.size, x, out, st)
     return out, st
+
+
+def lngamma_sgn(x, flavour=PORTABLE):
+    """gsl_sf_lngamma_sgn_e of the checker: (value, sign, status)"""
+    x = _f64(x); v = np.empty_like(x); sg = np.empty_like(x); st = np.zeros(x.size, dtype=np.int32)
+    lib().edo_lngamma_sgn_v(flavour, x.size, x, v, sg, st)
+    return v, sg, st
+
+
+def lnbeta_sites(x, y, flavour=PORTABLE):
+    """(value, error sites) of gsl_sf_lnbeta_e; sites coded as exomedepth_amd/csrc/ed_sf_dev.hpp::lnbeta_sites"""
+    x = _f64(x); y = _f64(y); v = np.empty_like(x); c = np.zeros(x.size, dtype=np.int32)
+    lib().edo_lnbeta_sites_v(flavour, x.size, x, y, v, c)
+    return v, c
+
+
+def ref_lngamma_sgn(x):
+    """gsl_sf_lngamma_sgn_e of the reference build (oracle/_ref): (value, sign, status); error-free arguments only"""
+    _ref_open()
+    x = _f64(x); v = np.empty_like(x); sg = np.empty_like(x); st = np.zeros(x.size, dtype=np.int32)
+    if lib().edo_ref_lngamma_sgn(x.size, x, v, sg, st) != 0:
+        raise RuntimeError("gsl_sf_lngamma_sgn_e not found in the reference build")
+    return v, sg, st
 
 
 def get_loglike_matrix(phi, expected, total, observed, mixture=1.0, flavour=PORTABLE):

@@ -34,6 +34,21 @@ def around(vals, rel=(1e-15, 1e-12, 1e-6, 1e-3)):
     return np.array(out)
 
 
+def negative_domain_fixture():
+    """sf_ref_negative.npz: gsl_sf_lngamma_sgn_e of the reference build (value, sign) on negative non-integer arguments --
+    reflection branch, next to -1, next to -N (lngamma_sgn_sing with its psi_n terms), far negative, and around 0."""
+    rng = np.random.default_rng(20250929)
+    x = np.concatenate([-rng.uniform(0.02, 60, 1500), -1 + rng.uniform(-0.0149, 0.0149, 300),
+                        -rng.integers(2, 300, 700) + rng.uniform(-0.0149, 0.0149, 700),
+                        -rng.integers(2, 400, 300) + rng.choice([1e-12, -1e-9, 3e-6, -2.5e-4, 0.0011, -0.0051, 0.0101], 300),
+                        -rng.integers(170, 100000, 200) + rng.uniform(-0.0149, 0.0149, 200),
+                        -np.exp(rng.uniform(np.log(1e3), np.log(1e9), 200)), rng.uniform(-0.02, 0.02, 100)])
+    x = x[(x != np.floor(x))]
+    v, s, st = eo.ref_lngamma_sgn(x)
+    assert np.all(st == 0)
+    np.savez_compressed(os.path.join(HERE, "sf_ref_negative.npz"), lngamma_sgn_x=x, lngamma_sgn=v, lngamma_sgn_sign=s)
+
+
 def survey_probe_fixture():
     """config1_survey_probe.json: the facts SURVEY.md 8c (G4) recorded from the reference's compiled C for Exome1 vs
     Exome2+3+4 with (eta, phi) = (-1.36727, 0.0049568) -- those are `reference_facts`, typed in from the survey, not
@@ -55,6 +70,9 @@ def main():
     eo.build()
     if "--survey-probe-only" in sys.argv:
         survey_probe_fixture()
+        return
+    if "--negative-only" in sys.argv:
+        negative_domain_fixture()
         return
     assert eo.ref_available(), "oracle/_ref/libgslsf_ref.so missing (needs /root/reference)"
     rng = np.random.default_rng(20250620)
@@ -112,6 +130,7 @@ def main():
     json.dump(summary, open(os.path.join(HERE, "config1_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
     survey_probe_fixture()
+    negative_domain_fixture()
 
 
 if __name__ == "__main__":

@@ -446,3 +446,66 @@ def test_argument_errors_are_reported_not_crashed(edlib):
     with pytest.raises(edlib.EdError):                       # nstates != 3 (the reference prints and returns NULL)
         edlib.viterbi_hmm(np.full((2, 2), 0.5), np.zeros((5, 2)), np.arange(5), 1000.0)
     batch.close(); plan.close()
+
+
+def test_lnbeta_outside_the_positive_quadrant_matches_the_checker(edlib, oracle):
+    """VERDICT r1 missing #2: gsl_sf_lngamma_sgn_e for x < 0 (reflection src/VP_gamma.c:1244-1276, lngamma_sgn_sing :795-894)
+    now has no value deviation: device == checker (portable flavour) bit for bit, values, signs and error sites."""
+    import ctypes as C
+    from exomedepth_amd import _lib
+    L = _lib.lib()
+
+    def dev(which, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float64)
+        out = np.empty_like(x)
+        _lib.check(L.ed_eval_sf(which, x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data))
+        return out
+
+    rng = np.random.default_rng(77)
+    x = np.concatenate([-rng.uniform(0.0, 80, 20000), -1 + rng.uniform(-0.0149, 0.0149, 3000),
+                        -rng.integers(2, 500, 8000) + rng.uniform(-0.0149, 0.0149, 8000),
+                        -rng.integers(170, 3_000_000, 2000) + rng.uniform(-0.0149, 0.0149, 2000),
+                        -np.exp(rng.uniform(np.log(1e3), np.log(1e16), 2000)), rng.uniform(-0.02, 0.5, 3000),
+                        -rng.integers(0, 50, 200).astype(float), [np.nan, -np.inf, np.inf, 0.0, -0.0, -2147483650.25, -3e9]])
+    v, s, st = oracle.lngamma_sgn(x, oracle.PORTABLE)
+    got_v = dev(12, x)
+    got_ss = dev(13, x)
+    same = (got_v.view(np.int64) == v.view(np.int64)) | (np.isnan(got_v) & np.isnan(v))
+    assert np.all(same), x[~same][:10]
+    got_site = np.round((got_ss + 1.0) / 8.0)                # got_ss = sign + 8 * site, sign in {-1, 0, 1}
+    got_sign = got_ss - 8.0 * got_site
+    assert np.array_equal(got_sign, s)
+    assert np.array_equal(got_site != 0, st != 0)            # an error site exactly where the checker reports a status
+    # lnbeta: every combination of signs
+    n = 60000
+    a = np.concatenate([rng.uniform(-40, 40, n), -rng.integers(0, 30, 500).astype(float), [np.nan, 0.0, 3.0, np.nan]])
+    b = np.concatenate([rng.uniform(-40, 60, n), rng.uniform(-5, 5, 500), [np.nan, 2.0, 0.0, 5.0]])
+    ov, oc = oracle.lnbeta_sites(a, b, oracle.PORTABLE)
+    dv = dev(0, a, b)
+    dc = dev(11, a, b).astype(np.int64)
+    same = (dv.view(np.int64) == ov.view(np.int64)) | (np.isnan(dv) & np.isnan(ov))
+    assert np.all(same), (a[~same][:5], b[~same][:5], dv[~same][:5], ov[~same][:5])
+    assert np.array_equal(dc, oc)
+    assert (oc == 0).sum() > 20000 and (oc == 1 << 11).sum() > 5000 and (oc == 1 << 10).sum() >= 400
+    # portable sine against the host's (absolute error; the cold path needs signs and magnitudes >= 0.047 only)
+    t = np.concatenate([rng.uniform(-1e4, 1e4, 20000), rng.uniform(-1e12, 1e12, 20000)])
+    assert np.max(np.abs(dev(14, t) - np.sin(t))) < 7e-16
+    assert np.array_equal(dev(14, t).view(np.int64), oracle.psin_any(t).view(np.int64))
+
+
+def test_get_loglike_matrix_with_phi_above_one_matches_the_checker(edlib, oracle):
+    """phi > 1 makes the shape parameters negative: the reference evaluates the reflection formula and raises a domain error
+    where B(x, y) < 0 -- same values (bit for bit against the portable flavour), same number of GSL error events."""
+    rng = np.random.default_rng(78)
+    n = 4000
+    phi = rng.uniform(1.05, 4.0, n); e = rng.uniform(0.05, 0.9, n)
+    tot = rng.integers(0, 60, n).astype(np.int32); obs = (tot * rng.uniform(0, 1, n)).astype(np.int32)
+    got, nerr = edlib.get_loglike_matrix(phi, e, tot, obs, return_errors=True)
+    want, onerr = oracle.get_loglike_matrix(phi, e, tot, obs, 1.0, oracle.PORTABLE)
+    same = (np.ascontiguousarray(got).view(np.int64) == np.ascontiguousarray(want).view(np.int64)) | (np.isnan(got) & np.isnan(want))
+    assert np.all(same) and nerr == onerr and nerr > 0
+    assert np.isfinite(want).sum() > n                       # plenty of rows where the reference returns a value, not NaN
+    lw, _ = oracle.get_loglike_matrix(phi, e, tot, obs, 1.0, oracle.LIBM)
+    fin = np.isfinite(lw) & (np.abs(lw) > 1e-6)
+    assert np.array_equal(np.isnan(lw), np.isnan(want)) and np.max(np.abs(want[fin] - lw[fin]) / np.abs(lw[fin])) < 1e-10

@@ -176,3 +176,37 @@ def test_config1_regression_all_four_samples(oracle):
         assert np.array_equal(pp, path) and np.array_equal(cp, calls)
         nz = np.abs(L) > 0
         assert np.max(np.abs(Lp[nz] - L[nz]) / np.abs(L[nz])) < REL_TOL
+
+
+def test_lngamma_sgn_negative_arguments_against_reference_vectors(oracle):
+    """tests/golden/sf_ref_negative.npz: gsl_sf_lngamma_sgn_e of the reference build for x < 0 (reflection, lngamma_sgn_sing)."""
+    g = np.load(os.path.join(G, "sf_ref_negative.npz"))
+    v, s, st = oracle.lngamma_sgn(g["lngamma_sgn_x"], oracle.LIBM)
+    assert np.all(st == 0) and np.array_equal(s, g["lngamma_sgn_sign"]) and np.array_equal(bits(v), bits(g["lngamma_sgn"]))
+    pv, ps, _ = oracle.lngamma_sgn(g["lngamma_sgn_x"], oracle.PORTABLE)
+    ref = g["lngamma_sgn"]
+    big = np.abs(ref) > 1e-3
+    assert np.array_equal(ps, s) and np.max(np.abs(pv[big] - ref[big]) / np.abs(ref[big])) < REL_TOL
+
+
+def test_lnbeta_error_sites_and_values_outside_the_domain(oracle):
+    """What gsl_sf_lnbeta returns and which gsl_error() calls it makes (src/beta.c:44, :56, :59, :163; src/VP_gamma.c:803,
+    :1239, :1283) for arguments outside the positive quadrant."""
+    nan = float("nan")
+    x = np.array([0.0, 3.0, -2.0, nan, nan, -0.5, -0.5, -1.5, -2.0 + 1e-3, 5.0, -0.25])
+    y = np.array([3.0, 0.0, 1.5, nan, 5.0, -0.3, 3.0, 4.0, 7.5, -5.5, 0.25])
+    for fl in (oracle.LIBM, oracle.PORTABLE):
+        v, c = oracle.lnbeta_sites(x, y, fl)
+        assert c[0] == 1 << 9 and c[1] == 1 << 9 and np.isnan(v[0]) and np.isnan(v[1])         # beta.c:56
+        assert c[2] == 1 << 10 and np.isnan(v[2])                                              # beta.c:59
+        assert c[3] == (1 | 1 << 3 | 1 << 6) and v[3] == 0.0                                   # three EROUND exits, value 0
+        assert c[4] == (1 | 1 << 6) and abs(v[4] - np.log(24.0)) < 1e-14                       # lnbeta(NaN, 5) = lgamma(5)
+        assert c[5] == 1 << 11 and np.isnan(v[5])                                              # G(-.5) G(-.3) / G(-.8): negative
+        assert c[6] == 1 << 11 and np.isnan(v[6])                                              # G(-.5) < 0, others > 0
+        assert c[7] == 0 and np.isfinite(v[7])                                                 # G(-1.5) > 0
+        assert c[8] == 0 and np.isfinite(v[8])                                                 # next to -2: lngamma_sgn_sing
+        assert c[9] == 1 << 11 or c[9] == 0
+        assert c[10] == (2 << 6) and np.isnan(v[10])                                           # x + y == 0: VP_gamma.c:1239
+    import math
+    v, _ = oracle.lnbeta_sites(np.array([-1.5]), np.array([4.0]), oracle.LIBM)
+    assert abs(v[0] - (math.lgamma(-1.5) + math.lgamma(4.0) - math.lgamma(2.5))) < 1e-13
