@@ -56,6 +56,7 @@ SYMBOLS = [
     ("ed_batch_destroy", None, [_vp]),
     ("ed_batch_fit", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("ed_batch_set_fit_histograms", C.c_int, [_vp, C.c_int]),
+    ("ed_batch_fit_n_unconverged", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32)]),
     ("ed_batch_fit_subset", C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     ("ed_batch_fit_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     ("ed_batch_run_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
@@ -87,6 +88,7 @@ SYMBOLS = [
     ("ed_refset_finalize", C.c_int, [_vp, _i64, C.POINTER(_i32)]),
     ("ed_refset_thin_positions", C.c_int, [_i64, _i64, _vp, _i64, C.POINTER(_i64)]),
     ("ed_get_power_betabinom", C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    ("ed_get_power_betabinom_mode", C.c_int, [_i64, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     ("ed_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
     ("ed_free", C.c_int, [_vp]),
     ("ed_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t]),

@@ -256,6 +256,12 @@ class Batch:
         self._keep_fit = keep
         check(lib().ed_batch_fit_subset(self.handle, pt, pr, int(by), pp, pe, C.c_void_p(stream or 0)))
 
+    def fit_unconverged(self):
+        """(number of samples whose last fit() did not converge, first such sample or -1); synchronises the fit"""
+        n, first = C.c_int64(0), C.c_int32(-1)
+        check(lib().ed_batch_fit_n_unconverged(self.handle, C.byref(n), C.byref(first)))
+        return n.value, first.value
+
     def run(self, test, ref, phi, expected, mixture=1.0, stream=None):
         """Emissions + Viterbi + call table.  Arguments may be torch CUDA tensors (used in place),
         DeviceArrays, or host arrays (uploaded).  Asynchronous on `stream`."""
@@ -641,14 +647,18 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
 
 
 def get_power_betabinom(size, my_phi, my_p, my_alt_p, theory=False, frequentist=False, limit=False):
-    """reference R/tools.R:128-166 (vectorised over its arguments).  Only the default mode is on the device."""
-    if theory or frequentist or limit:
-        raise NotImplementedError("get.power.betabinom: only theory = FALSE, frequentist = FALSE, limit = FALSE is implemented")
+    """reference R/tools.R:128-166 (vectorised over its arguments): the expected log10 Bayes factor.  theory=True is the
+    reference's binomial case (:137-142).  `frequentist` is accepted and ignored, as in the reference (it is never read).
+    limit=True (:145-153) is a Monte-Carlo estimate from 2000 draws of R's random generator: no deterministic counterpart."""
+    if limit and not theory:
+        raise NotImplementedError("get.power.betabinom(limit = TRUE) averages over 2000 draws of R's rbetabinom.ab: "
+                                  "stochastic in the reference, not reproducible without R's generator")
     size, my_phi, my_p, my_alt_p = np.broadcast_arrays(_f64(np.atleast_1d(size)), _f64(np.atleast_1d(my_phi)),
                                                        _f64(np.atleast_1d(my_p)), _f64(np.atleast_1d(my_alt_p)))
     size, my_phi, my_p, my_alt_p = (_f64(a) for a in (size, my_phi, my_p, my_alt_p))
     out = np.empty(size.size, dtype=np.float64)
-    check(lib().ed_get_power_betabinom(size.size, _ptr(size), _ptr(my_phi), _ptr(my_p), _ptr(my_alt_p), _ptr(out)))
+    check(lib().ed_get_power_betabinom_mode(size.size, _ptr(size), _ptr(my_phi), _ptr(my_p), _ptr(my_alt_p),
+                                            1 if theory else 0, _ptr(out)))
     return out if out.size > 1 else float(out[0])
 
 
@@ -738,6 +748,9 @@ def fit_betabin(test, reference):
         exp = DeviceArray(np.zeros(1))
         batch.fit(test.reshape(n, 1), reference.reshape(n, 1), phi, exp)
         check(lib().ed_synchronize(None))
+        if batch.fit_unconverged()[0]:
+            import warnings
+            warnings.warn("beta-binomial fit: the Newton iteration did not converge (phi, expected are its last iterate)")
         return float(phi.to_host()[0]), float(exp.to_host()[0])
     finally:
         batch.close()

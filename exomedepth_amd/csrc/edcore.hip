@@ -1721,6 +1721,7 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
   HIP_TRY(hipSetDevice(device));
   ed_plan* p = new (std::nothrow) ed_plan;
   if (!p) return ed_fail(ED_ERR_NOMEM, "out of host memory");
+  struct Guard { ed_plan* p; ~Guard() { if (p) ed_plan_destroy(p); } } guard{p};   // released on success only
   p->device = device; p->E = n_exons; p->C = n_chrom; p->tprob = transition_probability; p->L = expected_cnv_length;
   p->chrom_off.assign(chrom_off, chrom_off + n_chrom + 1);
   // transitions <- matrix(c(1-t, t/2, t/2, .5,.5,0, .5,0,.5), byrow=TRUE)  (R/class_definition.R:343-347),
@@ -1739,7 +1740,7 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
   for (int c = 0; c < n_chrom; ++c) p->max_words = std::max(p->max_words, tile_off[c + 1] - tile_off[c]);
   p->c0 = std::log(T[0]);   // log(1 - t): into normal from normal
   p->c1 = std::log(T[3]);   // log(t / 2): into a CNV state from normal (T[3] == T[6])
-  bool symmetric = (T[3] == T[6]);
+  bool symmetric = (T[3] == T[6]), out_of_range = false;
   {
     // one task per chromosome, spread over the host threads
     unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
@@ -1754,9 +1755,14 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
         pos.resize((size_t)m + 2);
         lt9.resize((size_t)(m + 1) * 9);
         // as.integer(c(positions[1] - 2*L, positions, end[last] + 2*L))  (R/class_definition.R:368)
-        pos[0] = (int32_t)((double)start[lo] - 2 * expected_cnv_length);
+        const double p_first = (double)start[lo] - 2 * expected_cnv_length, p_last = (double)end[hi - 1] + 2 * expected_cnv_length;
+        if (!(p_first > -2147483649.0 && p_first < 2147483648.0 && p_last > -2147483649.0 && p_last < 2147483648.0)) {
+          bad[tid] |= 2;      // (int32_t) of such a double is undefined behaviour; reported after the join
+          continue;
+        }
+        pos[0] = (int32_t)p_first;
         for (int64_t i = 0; i < m; ++i) pos[1 + i] = start[lo + i];
-        pos[m + 1] = (int32_t)((double)end[hi - 1] + 2 * expected_cnv_length);
+        pos[m + 1] = (int32_t)p_last;
         fill_log_transitions(T, expected_cnv_length, pos.data(), m + 2, lt9.data());
         double* o = lt3.data() + (size_t)(lo + c) * 8;
         for (int64_t g = 0; g <= m; ++g) {
@@ -1766,29 +1772,29 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
           o[g * 8 + 4] = q[7]; o[g * 8 + 5] = q[8]; o[g * 8 + 6] = q[1]; o[g * 8 + 7] = q[2];
           if (std::memcmp(&q[1], &q[2], 8) || std::memcmp(&q[4], &q[8], 8) || std::memcmp(&q[5], &q[7], 8) ||
               std::memcmp(&q[0], &p->c0, 8) || std::memcmp(&q[3], &p->c1, 8) || std::memcmp(&q[6], &p->c1, 8))
-            bad[tid] = 1;
+            bad[tid] |= 1;
         }
       }
     };
     for (unsigned tid = 1; tid < nt; ++tid) pool.emplace_back(work, tid);
     work(0);
     for (auto& th : pool) th.join();
-    for (char b : bad) if (b) symmetric = false;
+    for (char b : bad) { if (b & 1) symmetric = false; if (b & 2) out_of_range = true; }
   }
-  if (!symmetric) {
-    ed_plan_destroy(p);
+  if (!symmetric)
     return ed_fail(ED_ERR_STATE, "ed_plan_create: internal error, log-transition table is not symmetric");
-  }
+  if (out_of_range)
+    return ed_fail(ED_ERR_INVALID, "ed_plan_create: a padded position (first start - 2 L or last end + 2 L of a chromosome) does "
+                                   "not fit a 32-bit integer (R's as.integer() would give NA, R/class_definition.R:368)");
   hipError_t e1 = hipMalloc((void**)&p->d_lt3, lt3.size() * 8);
   hipError_t e2 = hipMalloc((void**)&p->d_chrom_off, (size_t)(n_chrom + 1) * 4);
   hipError_t e3 = hipMalloc((void**)&p->d_tile_off, (size_t)(n_chrom + 1) * 8);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-    ed_plan_destroy(p);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
     return ed_fail(ED_ERR_NOMEM, "ed_plan_create: device allocation failed");
-  }
   HIP_TRY(hipMemcpy(p->d_lt3, lt3.data(), lt3.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(p->d_chrom_off, chrom_off, (size_t)(n_chrom + 1) * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(p->d_tile_off, tile_off.data(), (size_t)(n_chrom + 1) * 8, hipMemcpyHostToDevice));
+  guard.p = nullptr;
   *plan = p;
   return ED_OK;
 }
@@ -1816,6 +1822,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   HIP_TRY(hipSetDevice(plan->device));
   ed_batch* b = new (std::nothrow) ed_batch;
   if (!b) return ed_fail(ED_ERR_NOMEM, "out of host memory");
+  struct Guard { ed_batch* b; ~Guard() { if (b) ed_batch_destroy(b); } } guard{b};   // released on success only
   b->plan = plan; b->S = n_samples;
   const int64_t E = plan->E, S = n_samples, C = plan->C;
   // capacity of the call table: generous for real data (a few hundred calls per sample); a run that needs more
@@ -1838,10 +1845,8 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   A((void**)&b->d_total, 8);
   A((void**)&b->d_nerr, 8);
   A((void**)&b->d_calls, (size_t)b->calls_cap * sizeof(ed_call));
-  if (!ok) {
-    ed_batch_destroy(b);
+  if (!ok)
     return ed_fail(ED_ERR_NOMEM, "ed_batch_create: device allocation failed (E=%lld S=%lld)", (long long)E, (long long)S);
-  }
   {
     // Viterbi jobs: one chromosome each, longest first, cut into a few GROUPS.  ed_batch_run issues the
     // emissions group by group; the Viterbi chains of a group start on a side stream as soon as that
@@ -1952,6 +1957,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     HIP_TRY(hipMemcpy(b->d_seg, b->seg.data(), b->seg.size() * 8, hipMemcpyHostToDevice));
   }
   for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+  guard.b = nullptr;
   *batch = b;
   return ED_OK;
 }
@@ -2203,6 +2209,12 @@ struct FitWork {
   }
   int alloc(int64_t E, int64_t S_)
   {
+    const int rc = alloc_impl(E, S_);
+    if (rc != ED_OK) release();     // nothing half-allocated stays behind
+    return rc;
+  }
+  int alloc_impl(int64_t E, int64_t S_)
+  {
     release();
     S = S_;
     E_max = E;
@@ -2319,6 +2331,25 @@ ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_
                            void* stream_)
 {
   return ed_batch_fit_subset(b, d_test, d_ref, 1, d_phi, d_expected, stream_);
+}
+
+// How the last dispersion fit of the batch ended: a sample whose Newton iteration used up its iteration budget without a
+// step below tolerance is reported, not silently returned (aod::betabin exposes optim()'s convergence code likewise).
+ED_EXPORT int ed_batch_fit_n_unconverged(ed_batch* b, int64_t* n_unconverged, int32_t* first_sample)
+{
+  if (!b || !n_unconverged) return ed_fail(ED_ERR_INVALID, "NULL argument");
+  if (!b->fitw || !b->fitw->done) return ed_fail(ED_ERR_STATE, "no ed_batch_fit has been issued on this batch");
+  HIP_TRY(hipSetDevice(b->plan->device));
+  HIP_TRY(hipStreamSynchronize(b->fit_stream));
+  std::vector<int> done((size_t)b->S);
+  HIP_TRY(hipMemcpy(done.data(), b->fitw->done, (size_t)b->S * 4, hipMemcpyDeviceToHost));
+  int64_t n = 0;
+  int32_t first = -1;
+  for (int64_t s = 0; s < b->S; ++s)
+    if (!done[s]) { if (first < 0) first = (int32_t)s; ++n; }
+  *n_unconverged = n;
+  if (first_sample) *first_sample = first;
+  return ED_OK;
 }
 
 ED_EXPORT const double* ed_batch_loglik(const ed_batch* b) { return (b && (b->keep_loglik || !b->fused)) ? b->d_loglik : nullptr; }

@@ -135,6 +135,10 @@ void ed_batch_destroy(ed_batch* batch);
  * d_test/d_ref: int32 [n_exons][n_samples] sample-minor DEVICE matrices. */
 int ed_batch_fit(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
                  void* stream);
+/* Convergence of the last ed_batch_fit / ed_batch_fit_subset: number of samples whose Newton iteration ended on its
+ * iteration budget instead of a step below tolerance (their phi / expected are the last iterate), and the first such
+ * sample (-1 if none).  Synchronises the fit's stream. */
+int ed_batch_fit_n_unconverged(ed_batch* batch, int64_t* n_unconverged, int32_t* first_sample);
 /* How ed_batch_fit iterates: 1 (default) on per-sample count histograms built in one pass over the counts
  * (every Newton iteration then costs ~9 000 digamma evaluations per sample instead of 3 x n_exons); 0 per cell on
  * every pass.  Same maximum; the two differ by summation order only.  The histograms come in three geometries (unit
@@ -309,6 +313,11 @@ int ed_refset_thin_positions(int64_t len, int64_t n_reduced, int64_t* positions,
  * frequentist = FALSE, limit = FALSE): the expected log10 Bayes factor sum_{x=0}^{size} dbetabinom(x; alt) log10 BF(x),
  * for n parameter sets at once.  HOST arrays; synchronous. */
 int ed_get_power_betabinom(int64_t n, const double* size, const double* phi, const double* p, const double* alt_p, double* out);
+/* The same with the reference's `theory` switch: theory != 0 is its binomial case (R/tools.R:137-142), the sum of
+ * dbinom(x; size, alt_p) * log10 of the binomial likelihood ratio (phi is not used; 0 < p, alt_p < 1).  `limit = TRUE`
+ * (:145-153) draws 2000 random variates from R's generator and has no deterministic counterpart. */
+int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi, const double* p, const double* alt_p,
+                                int theory, double* out);
 
 /* ---- utilities ---- */
 /* device memory through the library, for callers without a HIP binding (tests, R shim) */

@@ -35,6 +35,16 @@ def dbetabinom_ab_log(x, size, a, b):
             - eo.lnbeta(np.array([a]), np.array([b]), eo.LIBM)[0])
 
 
+def get_power_binom(size, my_p, my_alt_p):
+    """reference R/tools.R:137-142 (theory = TRUE): sum over 0:size of dbinom(x; alt) * log10 of the binomial likelihood ratio.
+    dbinom through scipy (R's nmath is not in the reference tree: parity unpinned, tolerance-level)."""
+    from scipy.stats import binom
+    x = np.arange(0, int(size) + 1)
+    la = binom.logpmf(x, int(size), my_alt_p)
+    l0 = binom.logpmf(x, int(size), my_p)
+    return float(np.sum(np.exp(la) * (np.log10(np.e) * (la - l0))))
+
+
 def get_power_betabinom(size, my_phi, my_p, my_alt_p):
     """reference R/tools.R:128-166 with theory = FALSE, limit = FALSE"""
     a = my_p * (1 - my_phi) / my_phi

@@ -97,3 +97,24 @@ def test_call_info_after_a_fit_reads_live_inputs(edlib):
     assert b.call_info().tobytes() == want.tobytes() and len(want) > 0
     del junk
     b.close(); plan.close()
+
+
+def test_fit_reports_convergence_and_plan_rejects_unrepresentable_padding(edlib):
+    from exomedepth_amd import synth
+    E, S, C = 4000, 30, 2
+    chrom_off, start, end = synth.exon_design(E, C, 4)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 4, n_segments=2, mean_depth=70.0)
+    plan = edlib.Plan(chrom_off, start, end)
+    b = edlib.Batch(plan, S)
+    dphi = edlib.DeviceArray(np.zeros(S)); dexp = edlib.DeviceArray(np.zeros(S))
+    with pytest.raises(edlib.EdError, match="no ed_batch_fit"):
+        b.fit_unconverged()
+    for mode in (1, 0):
+        b.set_fit_histograms(mode)
+        b.fit(test, ref, dphi, dexp)
+        assert b.fit_unconverged() == (0, -1)
+    b.close(); plan.close()
+    # as.integer(start - 2 L) would be NA in R (R/class_definition.R:368): an error here, not undefined behaviour
+    far = start.astype(np.int64) + (2**31 - 1 - int(end.max()) - 10)
+    with pytest.raises(edlib.EdError, match="does not fit a 32-bit integer"):
+        edlib.Plan(chrom_off, far.astype(np.int32), (far + (end - start)).astype(np.int32), 1e-4, 50000.0)

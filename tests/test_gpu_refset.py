@@ -103,8 +103,14 @@ def test_get_power_betabinom_standalone(edlib):
     assert abs(got[1]) < 1e-12                                     # identical hypotheses: no evidence expected
     assert got[0] > 1.0 and np.allclose(got, exp, rtol=1e-9, atol=1e-12), (got, exp)
     assert isinstance(edlib.get_power_betabinom(200, 0.1, 0.2, 0.6), float)
+    # theory = TRUE: the binomial case (R/tools.R:137-142)
+    got = edlib.get_power_betabinom(size[:5], phi[:5], p[:5], alt[:5], theory=True)
+    exp = np.array([ro.get_power_binom(int(s), q, a) for s, q, a in zip(size[:5], p[:5], alt[:5])])
+    assert abs(got[1]) < 1e-12 and np.allclose(got, exp, rtol=1e-9, atol=1e-12), (got, exp)
+    # a binomial separates the hypotheses better than an over-dispersed model of the same means
+    assert np.all(got[[0, 2, 3, 4]] > edlib.get_power_betabinom(size[:5], phi[:5], p[:5], alt[:5])[[0, 2, 3, 4]])
     with pytest.raises(NotImplementedError):
-        edlib.get_power_betabinom(200, 0.1, 0.2, 0.6, theory=True)
+        edlib.get_power_betabinom(200, 0.1, 0.2, 0.6, limit=True)
 
 
 # ---- BASELINE.json configs[4]: select.reference.set, 500 000 bins x 2048 candidate references ----
