@@ -216,6 +216,7 @@ def main():
     beta_fit = torch.empty((max(args.cov, 0) + 1, S), dtype=torch.float64, device=dev)
     edges_fit = torch.empty((max(args.phi_bins, 1) + 1, S), dtype=torch.float64, device=dev)
     step_no = [0]
+    emitted = [None] * n_batches     # per batch object: event on the main stream after its last run's emission launches
 
     def step():
         k = step_no[0] % n_batches
@@ -228,10 +229,18 @@ def main():
             b.fit_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit[0], stream=stream)
             b.run_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit[0], 1.0, stream=stream)
         elif args.fit:
+            if fit_stream is not main_stream and emitted[k] is not None:
+                # this fit overwrites (phi, expected) of the batch object's previous run, two steps back: not before that
+                # run's emission kernels -- which read the per-sample constants made from them -- are through.  (It also
+                # keeps the fit stream from running more than one batch ahead: fit(N+2) executes underneath emissions(N+1).)
+                fit_stream.wait_event(emitted[k])
             b.fit(test, ref, phi_fit[k], p_fit[k], stream=fit_stream.cuda_stream)
             if fit_stream is not main_stream:
                 main_stream.wait_stream(fit_stream)      # the emissions of this batch need its (phi, expected)
             b.run(test, ref, phi_fit[k], p_fit[k], 1.0, stream=stream)
+            if fit_stream is not main_stream:
+                emitted[k] = torch.cuda.Event()
+                emitted[k].record(main_stream)
         else:
             b.run(test, ref, phi, p, 1.0, stream=stream)
 

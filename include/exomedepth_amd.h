@@ -211,7 +211,10 @@ int ed_batch_n_emit_launches(const ed_batch* batch);
  *   - the next ed_batch_run on the SAME batch waits for them by itself (its buffers are reused).
  * Two batches used alternately on one stream, the dispersion fit of the next batch issued on a second stream while the
  * current one runs, give a two-deep pipeline: fit(N+1) and the tail of N execute underneath the VALU-bound emissions
- * of N / N+1 (bench.py does exactly this).  Results are unchanged bit for bit.  Not available in fused mode (ignored). */
+ * of N / N+1 (bench.py does exactly this).  Results are unchanged bit for bit.  Not available in fused mode (ignored).
+ * The caller owns the hazards on ITS buffers: d_phi / d_expected handed to ed_batch_run are read by the first kernels of
+ * that run, so a later fit that overwrites them must be ordered after those kernels (an event recorded on the run's
+ * stream after ed_batch_run returns is enough). */
 int ed_batch_set_async_tail(ed_batch* batch, int on);
 int ed_batch_wait(ed_batch* batch, void* stream);
 

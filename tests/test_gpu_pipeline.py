@@ -118,3 +118,21 @@ def test_fit_reports_convergence_and_plan_rejects_unrepresentable_padding(edlib)
     far = start.astype(np.int64) + (2**31 - 1 - int(end.max()) - 10)
     with pytest.raises(edlib.EdError, match="does not fit a 32-bit integer"):
         edlib.Plan(chrom_off, far.astype(np.int32), (far + (end - start)).astype(np.int32), 1e-4, 50000.0)
+
+
+def test_device_call_table_is_the_call_table(edlib):
+    """dist.device_call_table: the library's device-resident table wrapped as a torch tensor (what the RCCL gather sends)."""
+    torch = pytest.importorskip("torch")
+    from exomedepth_amd import synth, dist as eddist, api
+    E, S, C = 5000, 70, 4
+    chrom_off, start, end = synth.exon_design(E, C, 6)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 6, n_segments=5, mean_depth=90.0)
+    plan = edlib.Plan(chrom_off, start, end)
+    b = edlib.Batch(plan, S)
+    b.run(test, ref, phi, p)
+    t = eddist.device_call_table(b)
+    calls = b.calls()
+    assert t.is_cuda and t.dtype == torch.int32 and tuple(t.shape) == (len(calls), 6) and len(calls) > 0
+    assert np.array_equal(t.cpu().numpy(), np.ascontiguousarray(calls).view(np.int32).reshape(-1, 6))
+    assert np.array_equal(eddist.calls_to_tensor(calls, torch.device("cpu")).numpy(), t.cpu().numpy())
+    b.close(); plan.close()
