@@ -59,7 +59,10 @@ def build(force=False, verbose=False):
 
 
 # Diagnostic variants of the library (same sources, different code generation); never loaded by the package itself.
-VARIANTS = {"coldinline": ["-DED_COLD_INLINE"]}
+VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
+            # round 1's Horner step (coefficient as an "s" asm operand): contains the VALU-write-SGPR -> VALU-read hazard
+            # (tools/isa_hazard_scan.py); built only to demonstrate it on hardware next to the fixed library
+            "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"]}
 
 
 def variant_path(name):

@@ -185,14 +185,37 @@
 ED_PM_FN uint64_t ed_pm_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 ED_PM_FN double ed_pm_from_bits(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 ED_PM_FN double ed_pm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-/* fma(a, b, k) with a compile-time constant addend k (Horner steps).  Same operation, same bits; on the device the
- * constant is handed over in scalar registers: left to itself the compiler picks v_fmac_f64, whose addend must
- * already sit in the destination VGPRs, and spends two extra vector moves per coefficient to put it there. */
-#if defined(__HIP_DEVICE_COMPILE__)
+/* fma(a, b, k) with a compile-time constant addend k (Horner steps).  Same operation, same bits on host and device.
+ * On the device the constant is handed to v_fma_f64 in a scalar register pair: left to itself the compiler picks
+ * v_fmac_f64, whose addend must already sit in the destination VGPRs, and spends two extra vector moves per coefficient.
+ *
+ * The pair is written by two s_mov_b32 INSIDE the asm statement, from immediates.  Round 1 passed the constant as an
+ * "s" operand instead; short of SGPRs, the register allocator then parked such constants in VGPR lanes and reloaded them
+ * with v_readlane_b32 -- a VALU write of an SGPR -- directly in front of the asm, and gfx940/gfx950 need 2 wait states
+ * between a VALU write of an SGPR and a VALU read of it.  LLVM inserts those for its own instructions but does not look
+ * inside inline asm, so the fma could pick up the previous coefficient's high half: the one unreproduced log-likelihood
+ * mismatch of round 1 (tools/hazard_sgpr_repro.hip shows the hazard in isolation; tools/isa_hazard_scan.py and
+ * tests/test_isa_hazards.py keep the compiler's output free of it).  Here nothing but SALU ever writes s[28:29]
+ * (caller-saved in the AMDGPU calling convention, so out-of-line callees need not preserve them), and an SALU write
+ * followed by a VALU read is interlocked by the hardware. */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ED_PM_FMA_K_SGPR_OPERAND)
+/* DIAGNOSTIC VARIANT ONLY (libedcore_sgprasm.so, tools/soak_emission.py --variant sgprasm): round 1's form, kept so that the
+ * hazard can be shown on hardware against the fixed library.  Never part of the product build. */
 __device__ static __inline__ __attribute__((always_inline)) double ed_pm_fma_k(double a, double b, double k)
 {
   double d;
   __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+  return d;
+}
+#elif defined(__HIP_DEVICE_COMPILE__)
+__device__ static __inline__ __attribute__((always_inline)) double ed_pm_fma_k(double a, double b, double k)
+{
+  double d;
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, k);   /* folds to a constant once inlined */
+  __asm__("s_mov_b32 s28, %3\n\ts_mov_b32 s29, %4\n\tv_fma_f64 %0, %1, %2, s[28:29]"
+          : "=v"(d)
+          : "v"(a), "v"(b), "i"((unsigned)(u & 0xffffffffull)), "i"((unsigned)(u >> 32))
+          : "s28", "s29");
   return d;
 }
 #else

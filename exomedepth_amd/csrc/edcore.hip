@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
              const int* __restrict__ cflags, const int64_t* __restrict__ seg, int nseg, int64_t blk_base, int64_t S,
              uint32_t nsb, const double2* __restrict__ tab_gl, const double* __restrict__ tab_lg,
-             double* __restrict__ loglik, unsigned long long* __restrict__ nerr)
+             double* __restrict__ loglik, unsigned long long* __restrict__ nerr, int* __restrict__ cold_flag)
 {
   __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
   __shared__ double t_b[kEmitTasks];   // max (ratio route) or y
@@ -261,7 +261,13 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       const double mn = (x < y ? x : y);
       const double rat = mn / mx;
       const bool front = live && !empty && pos && (rat < 0.2);
-      const bool back = live && !empty && !front;
+      const bool back = live && !empty && pos && !front;
+      // A non-positive or NaN argument (phi >= 1, expected outside (0, 1), negative counts) takes the reference's general
+      // route through gsl_sf_lngamma_sgn_e's reflection / singular branches: a deep, register-hungry call tree.  This kernel
+      // does not contain it (its register allocation would be the callee's: 102 instead of 73, two waves per SIMD lost);
+      // such a task is left to k_emit_cold, which runs after the group's launches when this flag is up.
+      const bool cold = live && !empty && !pos;
+      if (cold) *cold_flag = 1;
       // wave-aggregated slot allocation
       const unsigned long long mf = __ballot(front), mb = __ballot(back);
       const unsigned long long below = (1ull << lane) - 1ull;
@@ -272,7 +278,7 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       }
       basef = __shfl(basef, 0, 64);
       baseb = __shfl(baseb, 0, 64);
-      int sl = empty ? -2 : -1;
+      int sl = empty ? -2 : (cold ? -3 : -1);
       // the gather itself is done by whichever thread evaluates the task: issued at the top of the route, its
       // result is needed ~100 instructions later, so the latency hides behind the task's own arithmetic
       const bool tabbed = (unsigned)obs < (unsigned)kEmitTab && pos;
@@ -304,9 +310,7 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       const double x = t_a[sl], y = t_b[sl];
       const uint32_t ti = t_i[sl];
       const double lgx = (ti != 0xffffffffu) ? tab_lg[ti] : ed_pm_nan();
-      int flag = 0;
-      t_a[sl] = (x > 0.0 && y > 0.0) ? edsf::lnbeta_general_pre(x, y, lgx, s_logt) : edsf::lnbeta_cold(x, y, &flag);
-      nflag += flag;
+      t_a[sl] = edsf::lnbeta_general_pre(x, y, lgx, s_logt);
     }
   }
   __syncthreads();
@@ -319,8 +323,42 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       for (int st = 0; st < 3; ++st) {
         const double c = consts[(st * 3 + 2) * S + s];
         const int sl = slot[k * 3 + st];
+        if (sl == -3) continue;                       // k_emit_cold writes this value
         const double v = t_a[sl < 0 ? 0 : sl];
         __builtin_nontemporal_store((sl == -2 ? c : v) - c, &loglik[(e * 3 + st) * S + s]);
+      }
+    }
+  }
+  if (nflag) atomicAdd(nerr, (unsigned long long)nflag);
+}
+
+// The tasks k_emit_batch left out: (cell, state) pairs with a non-positive or NaN log-Beta argument.  Launched after the
+// emission launches of every overlap group (jobs j0 .. j1-1 of the segment table) with a small fixed grid; returns at
+// once unless k_emit_batch raised the flag, else walks the group's cells and evaluates exactly those pairs with the full
+// general route of the reference (edsf::lnbeta_cold: reflection, lngamma_sgn_sing, sign rule, error sites).
+__global__ void __launch_bounds__(256)
+k_emit_cold(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
+            const int64_t* __restrict__ seg, int j0, int j1, int64_t S, double* __restrict__ loglik,
+            unsigned long long* __restrict__ nerr, const int* __restrict__ cold_flag)
+{
+  if (*cold_flag == 0) return;
+  int nflag = 0;
+  for (int j = j0; j < j1; ++j) {
+    const int64_t e0 = seg[3 * j + 1], e1 = seg[3 * j + 2];
+    const int64_t ncell = (e1 - e0) * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t e = e0 + i / S, s = i % S;
+      const int32_t obs = test[e * S + s];
+      const int32_t tot = obs + ref[e * S + s];
+      if (obs == 0 && tot == 0) continue;      // a cell without reads is c - c in k_emit_batch, whatever c is
+      for (int st = 0; st < 3; ++st) {
+        const double x = consts[(st * 3 + 0) * S + s] + (double)obs;
+        const double y = (consts[(st * 3 + 1) * S + s] + (double)tot) - (double)obs;
+        if (x > 0.0 && y > 0.0) continue;
+        int flag = 0;
+        const double v = edsf::lnbeta_cold(x, y, &flag);
+        loglik[(e * 3 + st) * S + s] = v - consts[(st * 3 + 2) * S + s];
+        nflag += flag;
       }
     }
   }
@@ -1843,7 +1881,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   A((void**)&b->d_counts, (size_t)S * std::max<int64_t>(C, 1) * 4);
   A((void**)&b->d_offsets, (size_t)S * std::max<int64_t>(C, 1) * 8);
   A((void**)&b->d_total, 8);
-  A((void**)&b->d_nerr, 8);
+  A((void**)&b->d_nerr, 16);   // [0..7] GSL error events, [8..11] "cold tasks were left out" flag of k_emit_batch
   A((void**)&b->d_calls, (size_t)b->calls_cap * sizeof(ed_call));
   if (!ok)
     return ed_fail(ED_ERR_NOMEM, "ed_batch_create: device allocation failed (E=%lld S=%lld)", (long long)E, (long long)S);
@@ -2076,7 +2114,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   b->stream = tail;
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
-  HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 8, st));
+  HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 16, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
   if (plain) {
     hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
@@ -2126,13 +2164,18 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
                            em.cov ? em.K : -1, em.beta, mixture, E, S, b->d_loglik,
                            b->d_nerr);
       }
+      int* cold_flag = reinterpret_cast<int*>(b->d_nerr + 1);
       if (head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
-                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr);
+                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr,
+                           cold_flag);
       if (nblk - head > 0)
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
                            b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik,
-                           b->d_nerr);
+                           b->d_nerr, cold_flag);
+      if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
+        hipLaunchKernelGGL(k_emit_cold, dim3(512), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_seg, j0, j1, S, b->d_loglik,
+                           b->d_nerr, cold_flag);
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
       hipStream_t side = b->sides[g % b->sides.size()];
       HIP_TRY(hipStreamWaitEvent(side, b->job_ev[g], 0));
