@@ -144,6 +144,9 @@ def main():
                     "an optional mode, not the headline configuration")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): two batches in flight (fit of the next batch and the Viterbi tail "
                     "of the previous one run underneath the emissions); 0: steps strictly one after the other")
+    ap.add_argument("--viterbi-overlap", type=int, default=0, help="pipelined mode only: 0 (default) = all emissions of a batch as one "
+                    "launch, its chains afterwards, next to the next batch's fit; 1 = chains of a chromosome group underneath "
+                    "the emissions of the following groups (the lone-batch schedule); -1 = the library's default")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
@@ -205,6 +208,8 @@ def main():
         b.set_fused(bool(args.fused))
         b.keep_loglik(bool(args.keep_loglik))
         b.set_async_tail(n_batches == 2)
+        if n_batches == 2 and args.viterbi_overlap >= 0:
+            b.set_viterbi_overlap(bool(args.viterbi_overlap))
     batch = batches[0]
     main_stream = torch.cuda.current_stream()
     fit_stream = torch.cuda.Stream(device=dev) if n_batches == 2 else main_stream

@@ -82,6 +82,7 @@ SYMBOLS = [
     ("ed_batch_stage_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("ed_batch_stage_ms_total", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
     ("ed_batch_set_async_tail", C.c_int, [_vp, C.c_int]),
+    ("ed_batch_set_viterbi_overlap", C.c_int, [_vp, C.c_int]),
     ("ed_batch_wait", C.c_int, [_vp, _vp]),
     ("ed_select_reference_set", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     ("ed_select_reference_set_part", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),

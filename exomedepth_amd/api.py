@@ -230,6 +230,11 @@ class Batch:
         caller's stream (two batches used alternately then overlap; see ed_batch_set_async_tail)."""
         check(lib().ed_batch_set_async_tail(self.handle, 1 if on else 0))
 
+    def set_viterbi_overlap(self, on=True):
+        """on (default): chains of a chromosome group run underneath the emissions of the next groups; off: all emissions,
+        then all chains (what a pipeline of batches wants, see ed_batch_set_viterbi_overlap)"""
+        check(lib().ed_batch_set_viterbi_overlap(self.handle, 1 if on else 0))
+
     def wait(self, stream=None):
         """make `stream` wait (on the device) for the last run() of this batch, asynchronous tail included"""
         check(lib().ed_batch_wait(self.handle, C.c_void_p(stream or 0)))

@@ -1488,7 +1488,9 @@ struct ed_batch {
   std::vector<int64_t> seg;        // host copy (+ one closing entry holding the total workgroup count)
   int32_t n_jobs = 0;
   std::vector<std::vector<int>> jobs;   // host copy: chromosomes of each Viterbi job
-  std::vector<int32_t> group_off;       // job ranges of the overlap groups
+  std::vector<int32_t> group_off;       // job ranges of the overlap groups (the set in use)
+  std::vector<int32_t> group_off_model; // ... as the cost model cut them (Viterbi of a group under the emissions of the next)
+  bool overlap_groups = true;           // false: ONE group -- all emissions, then all chains (ed_batch_set_viterbi_overlap)
   std::vector<hipStream_t> sides;       // side streams (groups round-robin): Viterbi overlaps the emissions of later groups
   std::vector<hipEvent_t> job_ev;       // emissions of group g are complete
   std::vector<hipEvent_t> join_ev;      // Viterbi (+ trace-back) of group g is complete
@@ -1964,6 +1966,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
       const double cost = std::max(t_main, finish);
       if (cost < best_cost) { best_cost = cost; b->group_off = goff; }
     }
+    b->group_off_model = b->group_off;
     std::vector<int32_t> joff(1, 0), jchr;
     for (auto& jb : jobs) { for (int c : jb) jchr.push_back(c); joff.push_back((int32_t)jchr.size()); }
     b->n_jobs = (int32_t)jobs.size();
@@ -2051,6 +2054,18 @@ ED_EXPORT int ed_batch_enable_timing(ed_batch* b, int enable)
   b->have_run_times = b->have_fit_time = false;
   for (double& t : b->stage_total) t = 0.0;
   b->n_runs_timed = b->n_fits_timed = 0;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_set_viterbi_overlap(ed_batch* b, int on)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  b->overlap_groups = on != 0;
+  if (b->overlap_groups) b->group_off = b->group_off_model;
+  else {
+    b->group_off.assign(1, 0);
+    if (b->n_jobs > 0) b->group_off.push_back(b->n_jobs);
+  }
   return ED_OK;
 }
 

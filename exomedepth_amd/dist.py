@@ -59,7 +59,7 @@ class _DevicePointer:
     """a raw device buffer as a __cuda_array_interface__ object (so that torch can wrap it without a copy through the host)"""
 
     def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), True), "version": 2}
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 def device_call_table(batch):

@@ -217,6 +217,12 @@ int ed_batch_n_emit_launches(const ed_batch* batch);
  * stream after ed_batch_run returns is enough). */
 int ed_batch_set_async_tail(ed_batch* batch, int on);
 int ed_batch_wait(ed_batch* batch, void* stream);
+/* Where the Viterbi chains of a batch run relative to ITS OWN emissions.  1 (default): the chromosomes are cut into a few
+ * groups and the chains of a group run underneath the emissions of the following groups (what a lone batch wants: only the
+ * last, short chains are exposed).  0: one group -- all emissions as one launch, then all chains.  Co-running chains and
+ * emissions costs the (VALU-bound) emissions about as much as it hides; in a pipeline of batches the chains of batch N are
+ * better run next to the dispersion fit of batch N+1, which leaves the VALUs idle: asynchronous tail + 0 here. */
+int ed_batch_set_viterbi_overlap(ed_batch* batch, int on);
 
 /* device-resident results of the last ed_batch_run */
 const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples] */
