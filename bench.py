@@ -251,9 +251,9 @@ def main():
 
     def finish():
         """final gather of the compact call tables (the path's only collective); every batch in flight is drained"""
-        n = 0
-        for b in batches[1:]:
-            n = b.n_calls()
+        for j, b in enumerate(batches):
+            if j < step_no[0] and j != (step_no[0] - 1) % n_batches:
+                b.n_calls()                               # (a batch object that has run: wait for its tail)
         last = batches[(step_no[0] - 1) % n_batches]
         if world > 1:
             # rows straight from the device table when the collectives run on the GPU (RCCL); through the host for gloo

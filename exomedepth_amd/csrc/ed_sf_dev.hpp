@@ -159,7 +159,7 @@ __device__ __forceinline__ double lngamma_lanczos(double x, const double* LT = n
     Ag += fdiv(9.984369578019570859563e-6, x + 7.0);
     Ag += fdiv(1.50563273514931155834e-7, x + 8.0);
     const double term1 = (x + 0.5) * plog_pos(fdiv(x + 7.5, EDSF_M_E), LT);
-    const double term2 = EDSF_LOGROOT2PI + plog_fast(Ag, LT);
+    const double term2 = EDSF_LOGROOT2PI + plog_pos(Ag, LT);   // 1 < Ag < 1400 for every x >= -0.5 here: a normal number
     return term1 + (term2 - 7.0);
   }
   double Ag = 0.99999999999980993227684700473478;
@@ -220,6 +220,7 @@ __device__ EDSF_COLD double lngamma_below_half(double x, bool zform)
 // log Gamma(x) for x > 0 with the reference's window selection (src/VP_gamma.c:1219-1242)
 __device__ __forceinline__ double lngamma_pos(double x, bool zform, const double* LT = nullptr)
 {
+  if (x > 2.01) return lngamma_lanczos(x, LT);   // beyond both Pade windows and 0.5: the usual case, one comparison
   if (fabs(x - 1.0) < 0.01) return lngamma_pade(x - 1.0, 0);
   if (fabs(x - 2.0) < 0.01) return lngamma_pade(x - 2.0, 1);
   if (x >= 0.5) return lngamma_lanczos(x, LT);
@@ -498,7 +499,17 @@ __device__ __forceinline__ double lnbeta_ratio_pre(double mn, double mx, double 
   const double gsb = (g < 0.0) ? -g : gammastar_pos(mx);
   const double gsxy = gammastar_pos(mn + mx);
   const double lnopr = log1plusx_ratio(rat);
-  const double lnpre = plog_fast((fdiv(gsa * gsb, gsxy) * EDSF_M_SQRT2) * EDSF_M_SQRTPI, LT);
+  const double pre = (fdiv(gsa * gsb, gsxy) * EDSF_M_SQRT2) * EDSF_M_SQRTPI;
+  // mn >= 1e-100 and mx <= 1e100 (one test per task) make rat, mn and the Gamma* quotient normal numbers (Gamma* of such an
+  // argument lies in (0.9, 1e51)): the three logarithms skip their own range tests.  Same function, same bits.
+  if (mn >= 1e-100 && mx <= 1e100) {
+    const double lnpre = plog_pos(pre, LT);
+    const double t1 = mn * plog_pos(rat, LT);
+    const double t2 = 0.5 * (have_mn ? l : plog_pos(mn, LT));
+    const double t3 = ((mn + mx) - 0.5) * lnopr;
+    return lnpre + ((t1 - t2) - t3);
+  }
+  const double lnpre = plog_fast(pre, LT);
   const double t1 = mn * plog_fast(rat, LT);
   const double t2 = 0.5 * (have_mn ? l : plog_fast(mn, LT));
   const double t3 = ((mn + mx) - 0.5) * lnopr;
