@@ -107,6 +107,27 @@ def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit, allcores=0):
             eo.fit_nm(test_h[:, s], ref_h[:, s])
         t_fit = (time.perf_counter() - t0) * (n_s / n_fit)   # extrapolated linearly to the n_s samples
     extra = {}
+    if eo.ref_available():
+        # The reference's OWN compiled gsl_sf_lnbeta (oracle/_ref, built from /root/reference/src as it lies) on the six
+        # log-Beta calls per cell of one sample, next to the port's time for the same sample: the port is not a slower
+        # stand-in.  (The loop around it -- myprob's ten lines, src/CNV_estimate.cpp:44-50 -- and hmm.cpp cannot be built
+        # without R's headers, hence kind = "port".)
+        s0 = 0
+        e = float(p[s0]); ph = float(phi[s0])
+        sd = np.sqrt(ph * e * (1 - e))
+        xs, ys = [], []
+        obs = test_h[:, s0].astype(np.float64); tot = (test_h[:, s0] + ref_h[:, s0]).astype(np.float64)
+        for odds in (0.5, 1.0, 1.5):
+            ep = e * odds / (e * odds + 1 - e)
+            a1 = ep * ep * (1 - ep) / (sd * sd) - ep
+            a2 = (1 - ep) / ep * a1
+            xs += [a1 + obs, np.full_like(obs, a1)]; ys += [a2 + tot - obs, np.full_like(obs, a2)]
+        x = np.concatenate(xs); y = np.concatenate(ys)
+        t0 = time.perf_counter(); eo.ref_call2("gsl_sf_lnbeta", x, y); t_ref = time.perf_counter() - t0
+        t0 = time.perf_counter(); eo.lnbeta(x, y, eo.LIBM); t_port = time.perf_counter() - t0
+        extra["reference_build_lnbeta"] = {"calls": int(x.size), "reference_s": t_ref, "port_s": t_port,
+                                           "note": "gsl_sf_lnbeta of oracle/_ref (the reference's sources compiled in place) vs the "
+                                                   "checker's libm flavour on the same %d arguments of one sample" % x.size}
     if allcores > 1:
         # the same work on every host core: one pinned worker per core, each timing its own samples (the reference is
         # single-threaded: reported for completeness)

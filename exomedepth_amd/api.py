@@ -526,7 +526,13 @@ class ExomeDepth:
 
     def CallCNVs(self, chromosome, start, end, name, transition_probability=1e-4, expected_CNV_length=50000):
         """reference R/class_definition.R:311-419: order exons, one Viterbi chain per chromosome,
-        call table with start.p/end.p (1-based, global), type, nexons, start, end, chromosome, id."""
+        call table with start.p/end.p (1-based, global), type, nexons, start, end, chromosome, id.
+
+        One intentional difference on UNSORTED input: the reference reorders x@test, x@reference, x@annotations and
+        x@likelihood (:327-336) but not x@expected / x@phi, and then indexes x@expected with the reordered positions
+        (:396) -- with a per-exon `expected` (covariates in the formula) its reads.expected is then summed over the wrong
+        exons.  Here phi and expected are reordered with everything else, so reads.expected belongs to the call's exons.
+        With the default formula (expected constant) the two agree."""
         if self.phi.size == 0:
             self.CNV_calls = []
             return self
