@@ -27,10 +27,31 @@ def _worker(core, barrier, queue, cols, chrom_off, start, end, fit):
     queue.put((core, time.perf_counter() - t0, len(cols)))
 
 
+def cpu_quota():
+    """CPU bandwidth the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None if unlimited or unknown.
+    A box can show 256 logical CPUs in its affinity mask and still be throttled to a dozen cores' worth of time."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def all_cores(test_h, ref_h, p, phi, chrom_off, start, end, fit, max_workers):
+    import math
     import multiprocessing as mp
 
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    n_affinity = len(cores)
+    quota = cpu_quota()
+    if quota is not None:
+        max_workers = min(max_workers, max(1, int(math.ceil(quota))))     # more workers than the quota only measure throttling
     cores = cores[:max_workers]
     n_s = test_h.shape[1]
     ctx = mp.get_context("spawn")
@@ -49,6 +70,7 @@ def all_cores(test_h, ref_h, p, phi, chrom_off, start, end, fit, max_workers):
     slowest = max(r[1] for r in res)
     n_done = sum(r[2] for r in res)
     return {"value": test_h.shape[0] * n_done / slowest, "unit": "exons*samples/s", "cores": len(cores),
+            "logical_cpus_in_affinity_mask": n_affinity, "cgroup_cpu_quota_cores": quota,
             "slowest_worker_s": slowest, "mean_worker_s": float(np.mean([r[1] for r in res])),
             "sample": "%d workers pinned one per logical core, one sample column of %d exons each, timed inside the workers "
                       "after a common barrier" % (len(cores), test_h.shape[0])}
