@@ -230,7 +230,7 @@ def main():
         b.keep_loglik(bool(args.keep_loglik))
         b.set_async_tail(n_batches == 2)
         if n_batches == 2 and args.viterbi_overlap >= 0:
-            b.set_viterbi_overlap(args.viterbi_overlap)
+            b.set_viterbi_overlap(bool(args.viterbi_overlap))
     batch = batches[0]
     main_stream = torch.cuda.current_stream()
     fit_stream = torch.cuda.Stream(device=dev) if n_batches == 2 else main_stream

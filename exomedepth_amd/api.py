@@ -233,7 +233,7 @@ class Batch:
     def set_viterbi_overlap(self, on=True):
         """on (default): chains of a chromosome group run underneath the emissions of the next groups; off: all emissions,
         then all chains (what a pipeline of batches wants, see ed_batch_set_viterbi_overlap)"""
-        check(lib().ed_batch_set_viterbi_overlap(self.handle, int(on)))
+        check(lib().ed_batch_set_viterbi_overlap(self.handle, 1 if on else 0))
 
     def wait(self, stream=None):
         """make `stream` wait (on the device) for the last run() of this batch, asynchronous tail included"""

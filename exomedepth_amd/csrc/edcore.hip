@@ -1490,7 +1490,6 @@ struct ed_batch {
   std::vector<std::vector<int>> jobs;   // host copy: chromosomes of each Viterbi job
   std::vector<int32_t> group_off;       // job ranges of the overlap groups (the set in use)
   std::vector<int32_t> group_off_model; // ... as the cost model cut them (Viterbi of a group under the emissions of the next)
-  std::vector<int32_t> group_off_two;   // ... two groups: the longest chromosomes up to 55 % of the exons, then the rest
   bool overlap_groups = true;           // false: ONE group -- all emissions, then all chains (ed_batch_set_viterbi_overlap)
   std::vector<hipStream_t> sides;       // side streams (groups round-robin): Viterbi overlaps the emissions of later groups
   std::vector<hipEvent_t> job_ev;       // emissions of group g are complete
@@ -1968,12 +1967,11 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
       if (cost < best_cost) { best_cost = cost; b->group_off = goff; }
     }
     b->group_off_model = b->group_off;
-    b->group_off_two = candidates[1];
     std::vector<int32_t> joff(1, 0), jchr;
     for (auto& jb : jobs) { for (int c : jb) jchr.push_back(c); joff.push_back((int32_t)jchr.size()); }
     b->n_jobs = (int32_t)jobs.size();
     b->jobs = jobs;
-    const size_t n_groups = std::max<size_t>(b->group_off.size() - 1, 2);   // (the two-group cut set must have its events too)
+    const size_t n_groups = std::max<size_t>(b->group_off.size() - 1, 1);
     b->sides.resize(std::min<size_t>(n_groups, kSideStreams));
     for (auto& sd : b->sides) HIP_TRY(hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
     b->job_ev.resize(n_groups);
@@ -2063,8 +2061,7 @@ ED_EXPORT int ed_batch_set_viterbi_overlap(ed_batch* b, int on)
 {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->overlap_groups = on != 0;
-  if (on == 2) b->group_off = b->group_off_two;
-  else if (b->overlap_groups) b->group_off = b->group_off_model;
+  if (b->overlap_groups) b->group_off = b->group_off_model;
   else {
     b->group_off.assign(1, 0);
     if (b->n_jobs > 0) b->group_off.push_back(b->n_jobs);
