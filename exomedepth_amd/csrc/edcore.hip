@@ -1487,13 +1487,6 @@ struct ed_batch {
   int64_t* d_seg = nullptr;        // emission segments in job order: (first workgroup, first exon, end exon) x n_jobs
   std::vector<int64_t> seg;        // host copy (+ one closing entry holding the total workgroup count)
   int32_t n_jobs = 0;
-  // Forward-pass jobs of the one-group schedule (ed_batch_set_viterbi_overlap(b, 0)): the chromosomes packed (longest
-  // processing time first) into at most SIMDs / waves-per-chromosome jobs, so that -- when all chains of the batch are
-  // launched together -- every wave has a SIMD to itself and the makespan is the longest chromosome's chain instead of that
-  // chain time-sliced against a short chromosome's wave on the same SIMD (1.4 -> 1.1 ms at 200 000 x 1024).
-  int32_t* d_vjob_off = nullptr;
-  int32_t* d_vjob_chrom = nullptr;
-  int32_t n_vjobs = 0;
   std::vector<std::vector<int>> jobs;   // host copy: chromosomes of each Viterbi job
   std::vector<int32_t> group_off;       // job ranges of the overlap groups (the set in use)
   std::vector<int32_t> group_off_model; // ... as the cost model cut them (Viterbi of a group under the emissions of the next)
@@ -1989,34 +1982,6 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     HIP_TRY(hipMalloc((void**)&b->d_job_chrom, std::max<size_t>(jchr.size(), 1) * 4));
     HIP_TRY(hipMemcpy(b->d_job_off, joff.data(), joff.size() * 4, hipMemcpyHostToDevice));
     if (!jchr.empty()) HIP_TRY(hipMemcpy(b->d_job_chrom, jchr.data(), jchr.size() * 4, hipMemcpyHostToDevice));
-    {
-      // packed forward-pass jobs (see ed_batch::d_vjob_off)
-      const int64_t waves_per_chrom = (S + kVitChains - 1) / kVitChains;
-      int32_t nb = (int32_t)std::max<int64_t>(1, (int64_t)simds / std::max<int64_t>(waves_per_chrom, 1));
-      nb = std::min<int32_t>(nb, std::max<int32_t>(J, 1));
-      std::vector<std::vector<int>> bins((size_t)nb);
-      std::vector<int64_t> load((size_t)nb, 0);
-      for (int k = 0; k < J; ++k) {                      // jobs are sorted by decreasing length: LPT
-        const int c = jobs[k][0];
-        const size_t bi = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
-        bins[bi].push_back(c);
-        load[bi] += plan->chrom_off[c + 1] - plan->chrom_off[c];
-      }
-      std::vector<size_t> ord(bins.size());
-      for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
-      std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t bb) { return load[a] > load[bb]; });
-      std::vector<int32_t> voff(1, 0), vchr;
-      for (size_t i : ord) {
-        if (bins[i].empty()) continue;
-        for (int c : bins[i]) vchr.push_back(c);
-        voff.push_back((int32_t)vchr.size());
-      }
-      b->n_vjobs = (int32_t)voff.size() - 1;
-      HIP_TRY(hipMalloc((void**)&b->d_vjob_off, voff.size() * 4));
-      HIP_TRY(hipMalloc((void**)&b->d_vjob_chrom, std::max<size_t>(vchr.size(), 1) * 4));
-      HIP_TRY(hipMemcpy(b->d_vjob_off, voff.data(), voff.size() * 4, hipMemcpyHostToDevice));
-      if (!vchr.empty()) HIP_TRY(hipMemcpy(b->d_vjob_chrom, vchr.data(), vchr.size() * 4, hipMemcpyHostToDevice));
-    }
     // emission segments: one per job (= chromosome), in job order, so that a whole group is ONE launch
     int64_t blk = 0;
     for (auto& jb : jobs) {
@@ -2044,7 +2009,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
-  void* ptrs[] = {b->d_vjob_off, b->d_vjob_chrom, b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -2230,14 +2195,9 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       hipStream_t side = b->sides[g % b->sides.size()];
       HIP_TRY(hipStreamWaitEvent(side, b->job_ev[g], 0));
       const dim3 gw((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)(j1 - j0));
-      if (!b->overlap_groups && b->n_vjobs > 0)   // one group: the packed jobs, every wave on a SIMD of its own
-        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)b->n_vjobs), dim3(kWave), 0,
-                           side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
-                           b->d_last, b->d_vjob_off, b->d_vjob_chrom, 0);
-      else
-        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
-                           side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
-                           b->d_last, b->d_job_off, b->d_job_chrom, j0);
+      hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
+                         side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
+                         b->d_last, b->d_job_off, b->d_job_chrom, j0);
       hipLaunchKernelGGL(k_tb_maps, gw, dim3(256), 0, side, b->d_bp, p->d_chrom_off, p->d_tile_off, S, b->d_job_off,
                          b->d_job_chrom, j0, b->d_maps);
       hipLaunchKernelGGL(k_tb_chain, dim3((unsigned)((S + kWave - 1) / kWave), (unsigned)(j1 - j0)), dim3(kWave), 0, side,
