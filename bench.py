@@ -168,7 +168,8 @@ def main():
     ap.add_argument("--viterbi-overlap", type=int, default=0, help="pipelined mode only: 0 (default) = all emissions of a batch as one "
                     "launch, its chains afterwards, next to the next batch's fit; 1 = chains of a chromosome group underneath "
                     "the emissions of the following groups (the lone-batch schedule); -1 = the library's default")
-    ap.add_argument("--fit-priority", type=int, default=-1, help="priority of the stream the fit runs on in pipelined mode (-1 = high, 0 = normal)")
+    ap.add_argument("--fit-priority", type=int, default=0, help="priority of the stream the fit runs on in pipelined mode (0 = normal; -1 = high: "
+                    "the fit then pushes into the running emission launch and costs it more than it saves, 12.2 against 11.5 ms)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
@@ -234,8 +235,6 @@ def main():
             b.set_viterbi_overlap(bool(args.viterbi_overlap))
     batch = batches[0]
     main_stream = torch.cuda.current_stream()
-    # (high priority: when batch N's emission launch drains, the dispatcher serves the fit of batch N+1 -- which the next
-    # emissions wait for -- before the chains of batch N, which nothing waits for)
     fit_stream = torch.cuda.Stream(device=dev, priority=args.fit_priority) if n_batches == 2 else main_stream
     stream = main_stream.cuda_stream
     phi_fit = [torch.empty(S, dtype=torch.float64, device=dev) for _ in batches]
