@@ -132,7 +132,7 @@ def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit, allcores=0):
         # the same work on every host core: one pinned worker per core, each timing its own samples (the reference is
         # single-threaded: reported for completeness)
         from oracle import cpu_bench
-        extra = {"all_cores": cpu_bench.all_cores(test_h, ref_h, p, phi, chrom_off, start, end, fit, allcores)}
+        extra["all_cores"] = cpu_bench.all_cores(test_h, ref_h, p, phi, chrom_off, start, end, fit, allcores)
     return {**extra, "value": cells / (t_emit + t_vit + t_fit), "unit": "exons*samples/s", "cores": 1, "kind": "port",
             "value_without_fit": cells / (t_emit + t_vit),
             "sample": "%d samples x %d exons of the same synthetic batch: emissions + Viterbi + call table with the "
