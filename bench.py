@@ -170,6 +170,7 @@ def main():
                     "the emissions of the following groups (the lone-batch schedule); -1 = the library's default")
     ap.add_argument("--fit-priority", type=int, default=0, help="priority of the stream the fit runs on in pipelined mode (0 = normal; -1 = high: "
                     "the fit then pushes into the running emission launch and costs it more than it saves, 12.2 against 11.5 ms)")
+    ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
@@ -204,6 +205,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.lib_variant:      # a diagnostic build of the library (exomedepth_amd/_build.py::VARIANTS), never the default
+        from exomedepth_amd import _build as _b, _lib as _l
+        _l.LIB_PATH = _b.variant_path(args.lib_variant)
     import exomedepth_amd as ed
     from exomedepth_amd import _build, dist as eddist
     if not os.path.exists(_build.LIB) and rank == 0:   # never-built tree: compile the HIP library (there is no other path)
