@@ -62,9 +62,7 @@ def build(force=False, verbose=False):
 VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             # round 1's Horner step (coefficient as an "s" asm operand): contains the VALU-write-SGPR -> VALU-read hazard
             # (tools/isa_hazard_scan.py); built only to demonstrate it on hardware next to the fixed library
-            "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"],
-            # tiles per emission workgroup (bench.py --lib-variant tilesN): the tuning experiment behind kEmitTiles
-            "tiles1": ["-DED_EMIT_TILES=1"], "tiles2": ["-DED_EMIT_TILES=2"], "tiles8": ["-DED_EMIT_TILES=8"]}
+            "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"]}
 
 
 def variant_path(name):

@@ -173,20 +173,13 @@ k_emit_tables(const double* __restrict__ consts, int64_t S, double2* __restrict_
 // array, all others from the back, so every wave of the evaluation phase but at most one runs a
 // single route.  Cells are numbered exon-major / sample-minor: a wave reads 64 consecutive samples of
 // one exon (coalesced) and writes three coalesced rows of the [E][3][S] likelihood matrix.
-constexpr int kEmitCells = 1;                                // cells per thread and tile
-constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per tile
-constexpr int kEmitTileRows = kEmitCells * kEmitBlock / 64;  // exons per tile (x 64 samples)
-#ifndef ED_EMIT_TILES
-#define ED_EMIT_TILES 4
-#endif
-constexpr int kEmitTiles = ED_EMIT_TILES;                    // tiles a workgroup walks one after the other (consecutive exons, same samples)
-constexpr int kEmitRows = kEmitTileRows * kEmitTiles;        // exons per workgroup
-constexpr int64_t kEmitHeadBlocks = 2048 / kEmitTiles;       // workgroups of a group's short leading launch (ed_batch_run)
+constexpr int kEmitCells = 1;                                // cells per thread
+constexpr int kEmitTasks = kEmitBlock * kEmitCells * 3;      // tasks per workgroup
+constexpr int kEmitRows = kEmitCells * kEmitBlock / 64;      // exons per workgroup tile (x 64 samples)
+constexpr int64_t kEmitHeadBlocks = 2048;                    // workgroups of a group's short leading launch (ed_batch_run)
 constexpr int kSideStreams = 3;                              // HIP maps streams onto 4 hardware queues: main + 3
 
-// (6 waves per SIMD = at most 80 VGPRs: what the 21.5 KB of LDS per workgroup allow anyway; said explicitly because with the
-// tile loop the compiler otherwise hoists its way to 108)
-__global__ void __launch_bounds__(kEmitBlock, 6)
+__global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
              const int* __restrict__ cflags, const int64_t* __restrict__ seg, int nseg, int64_t blk_base, int64_t S,
              uint32_t nsb, const double2* __restrict__ tab_gl, const double* __restrict__ tab_lg,
@@ -208,10 +201,10 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   }
   __syncthreads();
   // The batch's exons are cut into nseg segments of whole chromosomes (job order); seg[3*i .. 3*i+2] = (first
-  // workgroup, first exon, end exon) of segment i.  A workgroup owns kEmitRows exons x 64 samples, walked as kEmitTiles
-  // tiles of kEmitTileRows exons (a wave reads 64 consecutive samples of one exon; no per-cell division); inside a
-  // segment the workgroups are numbered exon-block major over nsb = ceil(S / 64) sample blocks.  This launch covers
-  // workgroups blk_base .. blk_base + gridDim.x - 1 of that numbering; a short uniform search finds the workgroup's segment.
+  // workgroup, first exon, end exon) of segment i.  A workgroup owns a tile of kEmitRows exons x 64 samples (a wave
+  // reads 64 consecutive samples of one exon; no per-cell division); inside a segment the workgroups are numbered
+  // exon-block major over nsb = ceil(S / 64) sample blocks.  This launch covers workgroups blk_base ..
+  // blk_base + gridDim.x - 1 of that numbering; a short uniform search finds the workgroup's segment.
   const int64_t blk = (int64_t)blockIdx.x + blk_base;
   int si = 0;
   while (si + 1 < nseg && seg[3 * (si + 1)] <= blk) ++si;
@@ -233,39 +226,22 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
     eb = local / nsb;
     sb = local - eb * nsb;
   }
-  const int64_t e_wg = seg[3 * si + 1] + (int64_t)eb * kEmitRows + (tid >> 6);   // this thread's exon in tile 0
+  const int64_t e_first = seg[3 * si + 1] + (int64_t)eb * kEmitRows + (tid >> 6);
   const int64_t s = (int64_t)sb * 64 + lane;
+  int slot[kEmitCells * 3];
   int nflag = 0;
-  // The counts of tile t + 1 are requested before tile t is worked on: a workgroup meets the HBM latency of its counts
-  // once, not once per tile, and is dispatched (and fills the log table) once per kEmitTiles tiles.
-  int32_t obs_n = 0, ref_n = 0;
-  {
-    const int64_t e = e_wg;
-    if ((e < e_end) && (s < S)) {
+  // ---- phase 1: classify and scatter the tasks ----
+#pragma unroll
+  for (int k = 0; k < kEmitCells; ++k) {
+    const int64_t e = e_first + (int64_t)k * (kEmitBlock / 64);
+    const bool live = (e < e_end) && (s < S);
+    int32_t obs = 0, tot = 0;
+    if (live) {
       const int64_t cell = e * S + s;
       // streamed once: keep them (and the likelihood rows below) from evicting the tables out of L2
-      obs_n = __builtin_nontemporal_load(&test[cell]);
-      ref_n = __builtin_nontemporal_load(&ref[cell]);
+      obs = __builtin_nontemporal_load(&test[cell]);
+      tot = obs + __builtin_nontemporal_load(&ref[cell]);   // as.integer(reference + test), R/class_definition.R:187
     }
-  }
-#pragma unroll 1
-  for (int t = 0; t < kEmitTiles; ++t) {
-    const int64_t e = e_wg + (int64_t)t * kEmitTileRows;
-    if (e - (tid >> 6) >= e_end) break;              // the segment ends inside this workgroup: uniform
-    const bool live = (e < e_end) && (s < S);
-    const int32_t obs = obs_n;
-    const int32_t tot = obs_n + ref_n;               // as.integer(reference + test), R/class_definition.R:187
-    {
-      const int64_t en = e + kEmitTileRows;
-      obs_n = 0; ref_n = 0;
-      if (t + 1 < kEmitTiles && (en < e_end) && (s < S)) {
-        const int64_t cell = en * S + s;
-        obs_n = __builtin_nontemporal_load(&test[cell]);
-        ref_n = __builtin_nontemporal_load(&ref[cell]);
-      }
-    }
-    int slot[3];
-    // ---- phase 1: classify and scatter the tasks ----
     // A cell without reads: a1 + 0 and (a2 + 0) - 0 are a1 and a2 themselves, so the reference's second log-Beta
     // call repeats the per-sample one bit for bit (same value, same GSL error) -- no task, the result is c - c
     // (exactly +0; NaN if c is not finite).  ~14 % of the exons of the bundled exome data have no reads.
@@ -315,41 +291,43 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
         sl = kEmitTasks - 1 - (baseb + __popcll(mb & below));
         t_a[sl] = x; t_b[sl] = y; t_r[sl] = rat; t_i[sl] = ti;
       }
-      slot[st] = sl;
+      slot[k * 3 + st] = sl;
     }
-    __syncthreads();
-    // ---- phase 2: evaluate; slots [0,nf) take the ratio route, slots [kEmitTasks-nb, kEmitTasks) the rest ----
-    const int nf = n_front, nb = n_back;
+  }
+  __syncthreads();
+  // ---- phase 2: evaluate; slots [0,nf) take the ratio route, slots [kEmitTasks-nb, kEmitTasks) the rest ----
+  const int nf = n_front, nb = n_back;
 #pragma unroll 1
-    for (int r = 0; r < kEmitCells * 3; ++r) {
-      const int sl = r * kEmitBlock + tid;
-      if (sl < nf) {
-        const uint32_t ti = t_i[sl];
-        double2 gl = make_double2(ed_pm_nan(), ed_pm_nan());
-        if (ti != 0xffffffffu) gl = tab_gl[ti & 0x7fffffffu];
-        if (ti & 0x80000000u) gl.x = -gl.x;
-        t_a[sl] = edsf::lnbeta_ratio_pre(t_a[sl], t_b[sl], t_r[sl], gl.x, gl.y, s_logt);
-      } else if (sl >= kEmitTasks - nb) {
-        const double x = t_a[sl], y = t_b[sl];
-        const uint32_t ti = t_i[sl];
-        const double lgx = (ti != 0xffffffffu) ? tab_lg[ti] : ed_pm_nan();
-        t_a[sl] = edsf::lnbeta_general_pre(x, y, lgx, s_logt);
-      }
+  for (int r = 0; r < kEmitCells * 3; ++r) {
+    const int sl = r * kEmitBlock + tid;
+    if (sl < nf) {
+      const uint32_t ti = t_i[sl];
+      double2 gl = make_double2(ed_pm_nan(), ed_pm_nan());
+      if (ti != 0xffffffffu) gl = tab_gl[ti & 0x7fffffffu];
+      if (ti & 0x80000000u) gl.x = -gl.x;
+      t_a[sl] = edsf::lnbeta_ratio_pre(t_a[sl], t_b[sl], t_r[sl], gl.x, gl.y, s_logt);
+    } else if (sl >= kEmitTasks - nb) {
+      const double x = t_a[sl], y = t_b[sl];
+      const uint32_t ti = t_i[sl];
+      const double lgx = (ti != 0xffffffffu) ? tab_lg[ti] : ed_pm_nan();
+      t_a[sl] = edsf::lnbeta_general_pre(x, y, lgx, s_logt);
     }
-    __syncthreads();
-    if (tid == 0) { n_front = 0; n_back = 0; }       // (everyone has read them; the barrier below orders this before the next tile)
-    // ---- phase 3: gather, subtract the per-sample constant, store ----
-    if (live) {
+  }
+  __syncthreads();
+  // ---- phase 3: gather, subtract the per-sample constant, store ----
+#pragma unroll
+  for (int k = 0; k < kEmitCells; ++k) {
+    const int64_t e = e_first + (int64_t)k * (kEmitBlock / 64);
+    if ((e < e_end) && (s < S)) {
 #pragma unroll
       for (int st = 0; st < 3; ++st) {
         const double c = consts[(st * 3 + 2) * S + s];
-        const int sl = slot[st];
+        const int sl = slot[k * 3 + st];
         if (sl == -3) continue;                       // k_emit_cold writes this value
         const double v = t_a[sl < 0 ? 0 : sl];
         __builtin_nontemporal_store((sl == -2 ? c : v) - c, &loglik[(e * 3 + st) * S + s]);
       }
     }
-    if (t + 1 < kEmitTiles) __syncthreads();          // the task arrays are rewritten by the next tile
   }
   if (nflag) atomicAdd(nerr, (unsigned long long)nflag);
 }
