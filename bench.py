@@ -170,6 +170,7 @@ def main():
                     "the emissions of the following groups (the lone-batch schedule); -1 = the library's default")
     ap.add_argument("--fit-priority", type=int, default=0, help="priority of the stream the fit runs on in pipelined mode (0 = normal; -1 = high: "
                     "the fit then pushes into the running emission launch and costs it more than it saves, 12.2 against 11.5 ms)")
+    ap.add_argument("--batches-in-flight", type=int, default=3, help="batch objects used in rotation by the pipelined schedule (>= 2)")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
@@ -228,18 +229,18 @@ def main():
     # dispersion fit of the next batch is issued on a second stream and the Viterbi tail / call table of the previous batch
     # finish on streams of its own (ed_batch_set_async_tail), so both execute underneath the VALU-bound emission kernels.
     # Every step still does the whole path on its batch; --pipeline 0 runs the steps strictly one after the other.
-    n_batches = 2 if (args.pipeline and plain and not args.fused) else 1
+    n_batches = max(2, args.batches_in_flight) if (args.pipeline and plain and not args.fused) else 1
     batches = [ed.Batch(plan, S) for _ in range(n_batches)]
     for b in batches:
         b.enable_timing(True)
         b.set_fused(bool(args.fused))
         b.keep_loglik(bool(args.keep_loglik))
-        b.set_async_tail(n_batches == 2)
-        if n_batches == 2 and args.viterbi_overlap >= 0:
+        b.set_async_tail(n_batches >= 2)
+        if n_batches >= 2 and args.viterbi_overlap >= 0:
             b.set_viterbi_overlap(bool(args.viterbi_overlap))
     batch = batches[0]
     main_stream = torch.cuda.current_stream()
-    fit_stream = torch.cuda.Stream(device=dev, priority=args.fit_priority) if n_batches == 2 else main_stream
+    fit_stream = torch.cuda.Stream(device=dev, priority=args.fit_priority) if n_batches >= 2 else main_stream
     stream = main_stream.cuda_stream
     phi_fit = [torch.empty(S, dtype=torch.float64, device=dev) for _ in batches]
     p_fit = [torch.empty(S, dtype=torch.float64, device=dev) for _ in batches]
@@ -289,6 +290,11 @@ def main():
             return int(g.shape[0]) if g is not None else 0
         return last.n_calls()
 
+    for _ in range(n_batches):        # setup: every batch object allocates its working set (likelihood matrix, fit workspace) once
+        step()
+    finish()
+    torch.cuda.synchronize()
+    step_no[0] = 0
     for _ in range(args.warmup):
         step()
     finish()
