@@ -62,9 +62,7 @@ def build(force=False, verbose=False):
 VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             # round 1's Horner step (coefficient as an "s" asm operand): contains the VALU-write-SGPR -> VALU-read hazard
             # (tools/isa_hazard_scan.py); built only to demonstrate it on hardware next to the fixed library
-            "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"],
-            # waves per SIMD the emission kernel is compiled for (bench.py --lib-variant occN): the experiment behind ED_EMIT_OCC
-            "occ6": ["-DED_EMIT_OCC=6"], "occ8": ["-DED_EMIT_OCC=8"]}
+            "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"]}
 
 
 def variant_path(name):

@@ -179,14 +179,7 @@ constexpr int kEmitRows = kEmitCells * kEmitBlock / 64;      // exons per workgr
 constexpr int64_t kEmitHeadBlocks = 2048;                    // workgroups of a group's short leading launch (ed_batch_run)
 constexpr int kSideStreams = 3;                              // HIP maps streams onto 4 hardware queues: main + 3
 
-// Occupancy is what this kernel lives on: a wave issues VALU work ~14 % of its residency (the rest is waiting for LDS, the
-// table gathers and the two barriers), so the SIMD's VALU-busy is about 14 % x waves per SIMD.  7 waves per SIMD need <= 72
-// VGPRs (what the compiler uses) and <= 22.8 KB of LDS per workgroup: hence min/max is not parked in LDS next to min and max
-// but recomputed by the thread that evaluates the task (18.4 KB: 8 workgroups per CU by LDS, 7 waves per SIMD by registers).
-#ifndef ED_EMIT_OCC
-#define ED_EMIT_OCC 7
-#endif
-__global__ void __launch_bounds__(kEmitBlock, ED_EMIT_OCC)
+__global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
              const int* __restrict__ cflags, const int64_t* __restrict__ seg, int nseg, int64_t blk_base, int64_t S,
              uint32_t nsb, const double2* __restrict__ tab_gl, const double* __restrict__ tab_lg,
@@ -194,6 +187,7 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
 {
   __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
   __shared__ double t_b[kEmitTasks];   // max (ratio route) or y
+  __shared__ double t_r[kEmitTasks];   // min/max
   __shared__ uint32_t t_i[kEmitTasks]; // where the task's tabulated terms are: index into tab_gl / tab_lg; bit 31: x is the
                                        // larger argument; 0xffffffff: not tabulated
   __shared__ double s_logt[ED_PM_LOGT_N * 3];   // the portable log's table (3 KB), see edsf::plog_pos
@@ -292,10 +286,10 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       if (front) {
         sl = basef + __popcll(mf & below);
         if (tabbed && !(x < y)) ti |= 0x80000000u;   // x is the larger argument (x == y: its Gamma* serves as Gamma*(mx))
-        t_a[sl] = mn; t_b[sl] = mx; t_i[sl] = ti;
+        t_a[sl] = mn; t_b[sl] = mx; t_r[sl] = rat; t_i[sl] = ti;
       } else if (back) {
         sl = kEmitTasks - 1 - (baseb + __popcll(mb & below));
-        t_a[sl] = x; t_b[sl] = y; t_i[sl] = ti;
+        t_a[sl] = x; t_b[sl] = y; t_r[sl] = rat; t_i[sl] = ti;
       }
       slot[k * 3 + st] = sl;
     }
@@ -311,8 +305,7 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       double2 gl = make_double2(ed_pm_nan(), ed_pm_nan());
       if (ti != 0xffffffffu) gl = tab_gl[ti & 0x7fffffffu];
       if (ti & 0x80000000u) gl.x = -gl.x;
-      const double mn = t_a[sl], mx = t_b[sl];
-      t_a[sl] = edsf::lnbeta_ratio_pre(mn, mx, mn / mx /* as classified: the same division, the same bits */, gl.x, gl.y, s_logt);
+      t_a[sl] = edsf::lnbeta_ratio_pre(t_a[sl], t_b[sl], t_r[sl], gl.x, gl.y, s_logt);
     } else if (sl >= kEmitTasks - nb) {
       const double x = t_a[sl], y = t_b[sl];
       const uint32_t ti = t_i[sl];
