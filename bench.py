@@ -170,7 +170,7 @@ def main():
                     "the emissions of the following groups (the lone-batch schedule); -1 = the library's default")
     ap.add_argument("--fit-priority", type=int, default=0, help="priority of the stream the fit runs on in pipelined mode (0 = normal; -1 = high: "
                     "the fit then pushes into the running emission launch and costs it more than it saves, 12.2 against 11.5 ms)")
-    ap.add_argument("--batches-in-flight", type=int, default=3, help="batch objects used in rotation by the pipelined schedule (>= 2)")
+    ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
