@@ -494,25 +494,28 @@ __device__ __forceinline__ double lnbeta_ratio(double mn, double mx, double rat)
 __device__ __forceinline__ double lnbeta_ratio_pre(double mn, double mx, double rat, double g, double l,
                                                    const double* LT = nullptr)
 {
+  // Order of evaluation: everything that does not need the handed-in (g, l) comes first -- in k_emit_batch they are a
+  // table gather issued just before this call, and the ~150 instructions of log1p, Gamma*(mn + mx) and log(rat) are what
+  // hides its latency.  (The operations and their operands are those of lnbeta_ratio; only their order in time differs.)
+  const double lnopr = log1plusx_ratio(rat);
+  const double gsxy = gammastar_pos(mn + mx);
+  const double t3 = ((mn + mx) - 0.5) * lnopr;
+  // mn >= 1e-100 and mx <= 1e100 (one test per task) make rat, mn and the Gamma* quotient normal numbers (Gamma* of such an
+  // argument lies in (0.9, 1e51)): the three logarithms skip their own range tests.  Same function, same bits.
+  const bool plain = (mn >= 1e-100 && mx <= 1e100);
+  const double t1 = mn * (plain ? plog_pos(rat, LT) : plog_fast(rat, LT));
+  // ---- from here on (g, l) are needed ----
   const bool have_mn = g > 0.0;
   const double gsa = have_mn ? g : gammastar_pos(mn);
   const double gsb = (g < 0.0) ? -g : gammastar_pos(mx);
-  const double gsxy = gammastar_pos(mn + mx);
-  const double lnopr = log1plusx_ratio(rat);
   const double pre = (fdiv(gsa * gsb, gsxy) * EDSF_M_SQRT2) * EDSF_M_SQRTPI;
-  // mn >= 1e-100 and mx <= 1e100 (one test per task) make rat, mn and the Gamma* quotient normal numbers (Gamma* of such an
-  // argument lies in (0.9, 1e51)): the three logarithms skip their own range tests.  Same function, same bits.
-  if (mn >= 1e-100 && mx <= 1e100) {
+  if (plain) {
     const double lnpre = plog_pos(pre, LT);
-    const double t1 = mn * plog_pos(rat, LT);
     const double t2 = 0.5 * (have_mn ? l : plog_pos(mn, LT));
-    const double t3 = ((mn + mx) - 0.5) * lnopr;
     return lnpre + ((t1 - t2) - t3);
   }
   const double lnpre = plog_fast(pre, LT);
-  const double t1 = mn * plog_fast(rat, LT);
   const double t2 = 0.5 * (have_mn ? l : plog_fast(mn, LT));
-  const double t3 = ((mn + mx) - 0.5) * lnopr;
   return lnpre + ((t1 - t2) - t3);
 }
 
@@ -520,9 +523,10 @@ __device__ __forceinline__ double lnbeta_ratio_pre(double mn, double mx, double 
 // (lgx handed in, from lngamma_pos(x, false) itself; NaN = not known)
 __device__ __forceinline__ double lnbeta_general_pre(double x, double y, double lgx_in, const double* LT = nullptr)
 {
-  const double lgx = (lgx_in == lgx_in) ? lgx_in : lngamma_pos(x, false, LT);
+  // the two terms that do not need the handed-in value first: they hide the latency of the gather it comes from
   const double lgy = lngamma_pos(y, false, LT);
   const double lgxy = lngamma_pos(x + y, false, LT);
+  const double lgx = (lgx_in == lgx_in) ? lgx_in : lngamma_pos(x, false, LT);
   return (lgx + lgy) - lgxy;
 }
 

@@ -194,22 +194,34 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   __shared__ int n_front, n_back;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  if (tid == 0) { n_front = 0; n_back = 0; }
-  {
-    const double T0[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
-    for (int i = tid; i < ED_PM_LOGT_N * 3; i += kEmitBlock) s_logt[i] = (&T0[0][0])[i];
-  }
-  __syncthreads();
   // The batch's exons are cut into nseg segments of whole chromosomes (job order); seg[3*i .. 3*i+2] = (first
   // workgroup, first exon, end exon) of segment i.  A workgroup owns a tile of kEmitRows exons x 64 samples (a wave
   // reads 64 consecutive samples of one exon; no per-cell division); inside a segment the workgroups are numbered
   // exon-block major over nsb = ceil(S / 64) sample blocks.  This launch covers workgroups blk_base ..
   // blk_base + gridDim.x - 1 of that numbering; a short uniform search finds the workgroup's segment.
   const int64_t blk = (int64_t)blockIdx.x + blk_base;
-  int si = 0;
-  while (si + 1 < nseg && seg[3 * (si + 1)] <= blk) ++si;
-  const uint32_t local = (uint32_t)(blk - seg[3 * si]);
-  const int64_t e_end = seg[3 * si + 2];
+  // the segment: the last one whose first workgroup is <= blk (the table is sorted).  Lane i looks at segment i and a
+  // ballot counts them -- one load latency instead of a chain of up to nseg dependent scalar loads; the triple of the
+  // segment found is then read off its lane.
+  int si;
+  int64_t seg_first, seg_e0, e_end;
+  {
+    const bool has = lane < nseg;
+    const int64_t f = has ? seg[3 * lane] : 0, a = has ? seg[3 * lane + 1] : 0, z = has ? seg[3 * lane + 2] : 0;
+    si = __popcll(__ballot(has && f <= blk)) - 1;       // seg[0] = 0 <= blk: at least one
+    if (nseg > 64) while (si + 1 < nseg && seg[3 * (si + 1)] <= blk) ++si;
+    if (si < 64) {
+      auto pick = [&](int64_t v) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, si);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), si);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+      };
+      seg_first = pick(f); seg_e0 = pick(a); e_end = pick(z);
+    } else {
+      seg_first = seg[3 * si]; seg_e0 = seg[3 * si + 1]; e_end = seg[3 * si + 2];
+    }
+  }
+  const uint32_t local = (uint32_t)(blk - seg_first);
   uint32_t eb, sb;
   if (nsb >= 8) {
     // XCD-aware numbering (workgroup i runs on XCD i % 8; every segment starts at a multiple of 8): XCD x works on
@@ -221,77 +233,108 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
     const uint32_t r = idx / (kEmitRun * 8), rem = idx % (kEmitRun * 8);
     eb = sup * kEmitRun + rem / 8;
     sb = (rem % 8) + 8 * r;
-    if (sb >= nsb || seg[3 * si + 1] + (int64_t)eb * kEmitRows >= e_end) return;   // uniform: before any barrier
+    if (sb >= nsb || seg_e0 + (int64_t)eb * kEmitRows >= e_end) return;   // uniform: before any barrier
   } else {
     eb = local / nsb;
     sb = local - eb * nsb;
   }
-  const int64_t e_first = seg[3 * si + 1] + (int64_t)eb * kEmitRows + (tid >> 6);
+  const int64_t e_first = seg_e0 + (int64_t)eb * kEmitRows + (tid >> 6);
   const int64_t s = (int64_t)sb * 64 + lane;
   int slot[kEmitCells * 3];
   int nflag = 0;
-  // ---- phase 1: classify and scatter the tasks ----
+  static_assert(kEmitCells == 1, "the slot allocation below handles one cell per thread");
+  // Everything this thread reads from memory is requested here, in one go and ahead of the workgroup's first barrier:
+  // the counts (HBM), the per-sample shape parameters and flags (L2) and the logarithm's table (L2) then cost the
+  // workgroup ONE exposed latency at its start instead of three in a row.
+  const bool live = (e_first < e_end) && (s < S);
+  int32_t obs = 0, nref = 0;
+  double pa1[3] = {0.0, 0.0, 0.0}, pa2[3] = {0.0, 0.0, 0.0};
+  int pcf[3] = {0, 0, 0};
+  if (live) {
+    const int64_t cell = e_first * S + s;
+    // streamed once: keep them (and the likelihood rows below) from evicting the tables out of L2
+    obs = __builtin_nontemporal_load(&test[cell]);
+    nref = __builtin_nontemporal_load(&ref[cell]);
 #pragma unroll
-  for (int k = 0; k < kEmitCells; ++k) {
-    const int64_t e = e_first + (int64_t)k * (kEmitBlock / 64);
-    const bool live = (e < e_end) && (s < S);
-    int32_t obs = 0, tot = 0;
-    if (live) {
-      const int64_t cell = e * S + s;
-      // streamed once: keep them (and the likelihood rows below) from evicting the tables out of L2
-      obs = __builtin_nontemporal_load(&test[cell]);
-      tot = obs + __builtin_nontemporal_load(&ref[cell]);   // as.integer(reference + test), R/class_definition.R:187
+    for (int st = 0; st < 3; ++st) {
+      pa1[st] = consts[(st * 3 + 0) * S + s];
+      pa2[st] = consts[(st * 3 + 1) * S + s];
+      pcf[st] = cflags[st * S + s];
     }
+  }
+  if (tid == 0) { n_front = 0; n_back = 0; }
+  {
+    const double T0[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+    for (int i = tid; i < ED_PM_LOGT_N * 3; i += kEmitBlock) s_logt[i] = (&T0[0][0])[i];
+  }
+  __syncthreads();
+  // ---- phase 1: classify and scatter the tasks ----
+  {
+    const int32_t tot = obs + nref;   // as.integer(reference + test), R/class_definition.R:187
     // A cell without reads: a1 + 0 and (a2 + 0) - 0 are a1 and a2 themselves, so the reference's second log-Beta
     // call repeats the per-sample one bit for bit (same value, same GSL error) -- no task, the result is c - c
     // (exactly +0; NaN if c is not finite).  ~14 % of the exons of the bundled exome data have no reads.
     const bool empty = live && obs == 0 && tot == 0;
+    const bool work = live && !empty;
+    double tx[3], ty[3], tr[3];
+    unsigned long long mf[3], mb[3];
+    bool cold_any = false;
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
       double x = 1.0, y = 1.0;
       if (live) {
-        const double a1 = consts[(st * 3 + 0) * S + s];
-        const double a2 = consts[(st * 3 + 1) * S + s];
-        x = a1 + (double)obs;                       // src/CNV_estimate.cpp:49
-        y = (a2 + (double)tot) - (double)obs;
-        nflag += cflags[st * S + s] * (empty ? 2 : 1);
+        x = pa1[st] + (double)obs;                       // src/CNV_estimate.cpp:49
+        y = (pa2[st] + (double)tot) - (double)obs;
+        nflag += pcf[st] * (empty ? 2 : 1);
       }
       const bool pos = (x > 0.0 && y > 0.0);
       const double mx = (x > y ? x : y);
       const double mn = (x < y ? x : y);
       const double rat = mn / mx;
-      const bool front = live && !empty && pos && (rat < 0.2);
-      const bool back = live && !empty && pos && !front;
+      const bool front = work && pos && (rat < 0.2);
+      const bool back = work && pos && !front;
       // A non-positive or NaN argument (phi >= 1, expected outside (0, 1), negative counts) takes the reference's general
       // route through gsl_sf_lngamma_sgn_e's reflection / singular branches: a deep, register-hungry call tree.  This kernel
       // does not contain it (its register allocation would be the callee's: 102 instead of 73, two waves per SIMD lost);
       // such a task is left to k_emit_cold, which runs after the group's launches when this flag is up.
-      const bool cold = live && !empty && !pos;
-      if (cold) *cold_flag = 1;
-      // wave-aggregated slot allocation
-      const unsigned long long mf = __ballot(front), mb = __ballot(back);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      int basef = 0, baseb = 0;
-      if (lane == 0) {
-        basef = atomicAdd(&n_front, __popcll(mf));
-        baseb = atomicAdd(&n_back, __popcll(mb));
+      const bool cold = work && !pos;
+      cold_any |= cold;
+      mf[st] = __ballot(front);
+      mb[st] = __ballot(back);
+      tx[st] = x;
+      ty[st] = y;
+      tr[st] = rat;
+      slot[st] = empty ? -2 : (cold ? -3 : (front ? 1 : (back ? 0 : -1)));
+    }
+    if (cold_any) *cold_flag = 1;
+    // wave-aggregated slot allocation: ONE pair of LDS atomics per wave for its (up to) 192 tasks
+    const int nf0 = __popcll(mf[0]), nf1 = __popcll(mf[1]), nb0 = __popcll(mb[0]), nb1 = __popcll(mb[1]);
+    int basef = 0, baseb = 0;
+    if (lane == 0) {
+      basef = atomicAdd(&n_front, nf0 + nf1 + __popcll(mf[2]));
+      baseb = atomicAdd(&n_back, nb0 + nb1 + __popcll(mb[2]));
+    }
+    basef = __builtin_amdgcn_readfirstlane(basef);
+    baseb = __builtin_amdgcn_readfirstlane(baseb);
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      const int kind = slot[st];   // 1 front, 0 back, < 0 no task
+      if (kind >= 0) {
+        const int offf = basef + (st > 0 ? nf0 : 0) + (st > 1 ? nf1 : 0);
+        const int offb = baseb + (st > 0 ? nb0 : 0) + (st > 1 ? nb1 : 0);
+        const int sl = kind ? offf + __popcll(mf[st] & below) : kEmitTasks - 1 - (offb + __popcll(mb[st] & below));
+        // the gather itself is done by whichever thread evaluates the task: issued at the top of the route, its
+        // result is needed ~100 instructions later, so the latency hides behind the task's own arithmetic
+        // (a task is here only if both arguments are positive; 3 * kEmitTab * S < 2^31 is checked by ed_batch_create)
+        uint32_t ti = ((unsigned)obs < (unsigned)kEmitTab) ? ((uint32_t)(st * kEmitTab + obs) * (uint32_t)S + (uint32_t)s) : 0xffffffffu;
+        const double x = tx[st], y = ty[st];
+        const bool swap = kind && !(x < y);   // ratio route takes (min, max); the general route (x, y)
+        // x = a1 + obs is what is tabulated: bit 31 says that it is the LARGER argument (x == y: its Gamma* serves as Gamma*(mx))
+        if (swap && ti != 0xffffffffu) ti |= 0x80000000u;
+        t_a[sl] = swap ? y : x; t_b[sl] = swap ? x : y; t_r[sl] = tr[st]; t_i[sl] = ti;
+        slot[st] = sl;
       }
-      basef = __shfl(basef, 0, 64);
-      baseb = __shfl(baseb, 0, 64);
-      int sl = empty ? -2 : (cold ? -3 : -1);
-      // the gather itself is done by whichever thread evaluates the task: issued at the top of the route, its
-      // result is needed ~100 instructions later, so the latency hides behind the task's own arithmetic
-      const bool tabbed = (unsigned)obs < (unsigned)kEmitTab && pos;
-      uint32_t ti = tabbed ? (uint32_t)(((int64_t)st * kEmitTab + obs) * S + s) : 0xffffffffu;
-      if (front) {
-        sl = basef + __popcll(mf & below);
-        if (tabbed && !(x < y)) ti |= 0x80000000u;   // x is the larger argument (x == y: its Gamma* serves as Gamma*(mx))
-        t_a[sl] = mn; t_b[sl] = mx; t_r[sl] = rat; t_i[sl] = ti;
-      } else if (back) {
-        sl = kEmitTasks - 1 - (baseb + __popcll(mb & below));
-        t_a[sl] = x; t_b[sl] = y; t_r[sl] = rat; t_i[sl] = ti;
-      }
-      slot[k * 3 + st] = sl;
     }
   }
   __syncthreads();
@@ -313,20 +356,22 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
       t_a[sl] = edsf::lnbeta_general_pre(x, y, lgx, s_logt);
     }
   }
+  // the per-sample constants of phase 3, requested before the barrier: their latency is spent waiting for the other waves
+  double pc[3] = {0.0, 0.0, 0.0};
+  if (live) {
+#pragma unroll
+    for (int st = 0; st < 3; ++st) pc[st] = consts[(st * 3 + 2) * S + s];
+  }
   __syncthreads();
   // ---- phase 3: gather, subtract the per-sample constant, store ----
+  if (live) {
 #pragma unroll
-  for (int k = 0; k < kEmitCells; ++k) {
-    const int64_t e = e_first + (int64_t)k * (kEmitBlock / 64);
-    if ((e < e_end) && (s < S)) {
-#pragma unroll
-      for (int st = 0; st < 3; ++st) {
-        const double c = consts[(st * 3 + 2) * S + s];
-        const int sl = slot[k * 3 + st];
-        if (sl == -3) continue;                       // k_emit_cold writes this value
-        const double v = t_a[sl < 0 ? 0 : sl];
-        __builtin_nontemporal_store((sl == -2 ? c : v) - c, &loglik[(e * 3 + st) * S + s]);
-      }
+    for (int st = 0; st < 3; ++st) {
+      const double c = pc[st];
+      const int sl = slot[st];
+      if (sl == -3) continue;                       // k_emit_cold writes this value
+      const double v = t_a[sl < 0 ? 0 : sl];
+      __builtin_nontemporal_store((sl == -2 ? c : v) - c, &loglik[(e_first * 3 + st) * S + s]);
     }
   }
   if (nflag) atomicAdd(nerr, (unsigned long long)nflag);
