@@ -63,15 +63,19 @@ def pmc_figures(meta, kernel, cells_per_step, kernel_cells_per_s):
         return {(r["kernel"], r["counter"]): (float(r["mean_per_launch"]), int(r["launches"])) for r in csv.DictReader(open(f))}
     out = {"profile": tag, "csrc_sha16": meta["csrc_sha16"]}
     fe, wr, sq, gr = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ"), load("GRBM_GUI_ACTIVE")
+    def runs(tab, counter):
+        # batch runs in that pass (timed + warm-up + the priming run of every batch object): k_sample_consts is launched
+        # exactly once per run, whatever the schedule
+        return float(tab[("k_sample_consts", counter)][1]) if ("k_sample_consts", counter) in tab else steps
     if (kernel, "FETCH_SIZE") in fe and (kernel, "WRITE_SIZE") in wr:
         f, n = fe[(kernel, "FETCH_SIZE")]
         w = wr[(kernel, "WRITE_SIZE")][0]
         out["traffic_bytes_per_launch"] = (2.0 * f + w) * 1024.0
-        out["traffic_bytes_per_step"] = (2.0 * f + w) * 1024.0 * n / steps
-        out["launches_per_step_profiled"] = n / steps
+        out["traffic_bytes_per_step"] = (2.0 * f + w) * 1024.0 * n / runs(fe, "FETCH_SIZE")
+        out["launches_per_step_profiled"] = n / runs(fe, "FETCH_SIZE")
     if (kernel, "SQ_INSTS_VALU") in sq and (kernel, "GRBM_GUI_ACTIVE") in gr:
         insts, n = sq[(kernel, "SQ_INSTS_VALU")]
-        per_cell = insts * n / steps / (cells_per_step / 64.0)          # lane-instructions per cell
+        per_cell = insts * n / runs(sq, "SQ_INSTS_VALU") / (cells_per_step / 64.0)          # lane-instructions per cell
         out["valu_lane_instructions_per_cell"] = per_cell
         out["valu_busy"] = sq[(kernel, "SQ_ACTIVE_INST_VALU")][0] * 4.0 / (gr[(kernel, "GRBM_GUI_ACTIVE")][0] / 8.0) / 1024.0
         out["salu_per_valu"] = sq[(kernel, "SQ_INSTS_SALU")][0] / insts if (kernel, "SQ_INSTS_SALU") in sq else None
