@@ -340,6 +340,13 @@ def main():
         n_launch = max(1, batch.n_emit_launches)   # one emission launch per overlap group of chromosomes (+ short head launches)
         kernel_cells_per_s = (E * S / t_emit) if t_emit else 0.0
         meta, why_not = matching_profile()
+        if meta:
+            # the counters describe the workload they were collected on: same exons x samples, same kernel, same number of
+            # emission launches per run (profiles/<tag>_meta.json "workload"); anything else gets no counter figures
+            w = meta.get("workload", {"exons": 200_000, "samples_per_gpu": 1024, "kernel": "k_emit_batch", "emission_launches_per_run": 1})
+            if (w.get("exons"), w.get("samples_per_gpu"), w.get("kernel"), w.get("emission_launches_per_run")) != (E, S, kernel, n_launch):
+                meta, why_not = None, ("profile %s was collected on %s: its counters are not quoted for this workload / schedule"
+                                       % (meta["tag"], json.dumps(w)))
         pmc = pmc_figures(meta, kernel, float(E) * S, kernel_cells_per_s) if meta else None
         traffic = pmc.get("traffic_bytes_per_step") / n_launch if pmc and "traffic_bytes_per_step" in pmc else None
         out = {

@@ -31,6 +31,8 @@ import json, sys, time
 sys.path.insert(0, ".")
 from exomedepth_amd import _build
 json.dump({"tag": sys.argv[2], "csrc_sha16": _build.csrc_sha16(), "pmc_steps": 3, "kernel_stats_steps": 6,
+           "workload": {"exons": 200000, "samples_per_gpu": 1024, "kernel": "k_emit_batch", "emission_launches_per_run": 1,
+                        "bench_flags": "defaults (pipelined, two batches in flight, fit on)"},
            "taken": time.strftime("%Y-%m-%d %H:%M:%S"), "bench_args": "--steps 2 --warmup 1 (PMC passes); --steps 5 --warmup 1 (kernel trace)"},
           open(sys.argv[1] + "/meta.json", "w"), indent=1)
 PY
