@@ -261,6 +261,13 @@ def test_batch_pipeline_parity_tumor_mixture_and_tiny(edlib, oracle, fused):
     _batch_vs_oracle(edlib, oracle, E=33, S=17, C=2, seed=8, fused=fused)   # a one-exon last tile, 2 ragged sample tiles
 
 
+def test_batch_more_than_64_chromosomes(edlib, oracle):
+    # k_emit_batch finds its segment with one ballot over 64 lanes; beyond 64 segments (one per non-empty chromosome)
+    # it walks on from there.  Both sample-block numberings: fewer than 8 blocks of 64 samples, and the XCD-aware one.
+    _batch_vs_oracle(edlib, oracle, E=2600, S=70, C=90, seed=21)
+    _batch_vs_oracle(edlib, oracle, E=1500, S=600, C=130, seed=22)
+
+
 def test_batch_empty_chromosomes(edlib, oracle):
     from exomedepth_amd import synth
     chrom_off = np.array([0, 0, 500, 500, 900], dtype=np.int32)   # chromosomes 0 and 2 are empty
