@@ -266,6 +266,26 @@ __device__ EDSF_COLD double gammastar_small(double x)
 
 __device__ __forceinline__ double gammastar_pos(double x) { return x >= 10.0 ? gammastar_large(x) : gammastar_small(x); }
 
+// The same recurrence for a FINITE argument, without the operations whose result is known: with d = dd = 0 the first step
+// (y2 * 0 - 0) + c[ORDER] is c[ORDER] itself (y2 * 0 is +-0 for finite y2, +-0 - 0 is +-0, and c[ORDER] != 0), and in the second
+// step "- dd" subtracts +0, an identity.  Four operations less, every remaining one unchanged: same bits.
+template <int ORDER>
+__device__ __forceinline__ double clenshaw_finite(const double* __restrict__ c, double x)
+{
+  static_assert(ORDER >= 2, "two steps are peeled");
+  const double y = ((2.0 * x + 1.0) - 1.0) / 2.0;
+  const double y2 = 2.0 * y;
+  double dd = c[ORDER];
+  double d = y2 * dd + c[ORDER - 1];
+#pragma unroll
+  for (int j = ORDER - 2; j >= 1; --j) {
+    const double t = d;
+    d = (y2 * d - dd) + c[j];
+    dd = t;
+  }
+  return (y * d - dd) + 0.5 * c[0];
+}
+
 // log(1+x) for 0 < x < 0.2 -- the only range lnbeta's ratio branch produces (src/VP_log.c:204-226)
 __device__ __forceinline__ double log1plusx_ratio(double x)
 {
@@ -276,7 +296,7 @@ __device__ __forceinline__ double log1plusx_ratio(double x)
     return x * (1.0 + x * (c1 + x * (c2 + x * (c3 + x * (c4 + x * t)))));
   }
   const double t = fdiv(0.5 * (8.0 * x + 1.0), x + 2.0);
-  return x * clenshaw<20>(k_lopx, t);
+  return x * clenshaw_finite<20>(k_lopx, t);   // t is a quotient of finite normal numbers
 }
 
 // ---- log|Gamma(x)| with sign for ANY x, as gsl_sf_lngamma_sgn_e computes it (src/VP_gamma.c:1219-1285) -- the cold

@@ -165,6 +165,22 @@ k_emit_tables(const double* __restrict__ consts, int64_t S, double2* __restrict_
   tab_lg[i] = lg;
 }
 
+// Raw buffer access: an SGPR resource (base pointer, size in bytes) + a 32-bit lane offset + a scalar offset.  Reads beyond
+// the size return 0, writes beyond it are dropped.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ed_rsrc(const void* base, int32_t bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double ed_buf_f64(__amdgpu_buffer_rsrc_t r, uint32_t voff, int32_t soff)
+{
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void ed_buf_store_f64_nt(__amdgpu_buffer_rsrc_t r, uint32_t voff, int32_t soff, double v)
+{
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 2);
+}
+
 // Emissions for the batch.  Each (cell, state) pair is one log-Beta *task*; a task takes one of two
 // value-exact routes (ratio / general, see ed_sf_dev.hpp) that differ ~1.5x in cost and that adjacent
 // cells pick differently (the selector is min/max < 0.2 of the shape parameters, src/beta.c:64-69).
@@ -238,8 +254,12 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
     eb = local / nsb;
     sb = local - eb * nsb;
   }
-  const int64_t e_first = seg_e0 + (int64_t)eb * kEmitRows + (tid >> 6);
-  const int64_t s = (int64_t)sb * 64 + lane;
+  // the wave's exon is wave-uniform (said explicitly: the compiler cannot know that tid >> 6 is), the sample is block + lane:
+  // every address below is a scalar base plus a 32-bit lane offset -- no 64-bit vector address arithmetic
+  const int wrow = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t e_first = seg_e0 + (int64_t)eb * kEmitRows + wrow;
+  const int64_t s0 = (int64_t)sb * 64;
+  const int64_t s = s0 + lane;
   int slot[kEmitCells * 3];
   int nflag = 0;
   static_assert(kEmitCells == 1, "the slot allocation below handles one cell per thread");
@@ -247,20 +267,27 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   // the counts (HBM), the per-sample shape parameters and flags (L2) and the logarithm's table (L2) then cost the
   // workgroup ONE exposed latency at its start instead of three in a row.
   const bool live = (e_first < e_end) && (s < S);
-  int32_t obs = 0, nref = 0;
-  double pa1[3] = {0.0, 0.0, 0.0}, pa2[3] = {0.0, 0.0, 0.0};
-  int pcf[3] = {0, 0, 0};
-  if (live) {
-    const int64_t cell = e_first * S + s;
-    // streamed once: keep them (and the likelihood rows below) from evicting the tables out of L2
-    obs = __builtin_nontemporal_load(&test[cell]);
-    nref = __builtin_nontemporal_load(&ref[cell]);
+  // Buffer addressing (SGPR resource + 32-bit lane offset + scalar row offset): no 64-bit vector address arithmetic, and
+  // the hardware's range check stands in for predication -- lanes beyond the sample block's end, or a whole wave beyond the
+  // segment's last exon, read zeros (and are masked out of the results by `live`).
+  const int32_t blk_samples = (int32_t)((S - s0 < 64) ? (S - s0) : 64);
+  const bool row_in = e_first < e_end;                          // scalar
+  const uint32_t l4 = (uint32_t)lane * 4u, l8 = (uint32_t)lane * 8u;
+  // streamed once (aux 2 = nt): keep the counts (and the likelihood rows below) from evicting the tables out of L2
+  const int32_t obs = __builtin_amdgcn_raw_buffer_load_b32(ed_rsrc(test + (e_first * S + s0), row_in ? blk_samples * 4 : 0), l4, 0, 2);
+  const int32_t nref = __builtin_amdgcn_raw_buffer_load_b32(ed_rsrc(ref + (e_first * S + s0), row_in ? blk_samples * 4 : 0), l4, 0, 2);
+  // consts [9][S] and flags [3][S]: one resource each from the block's first sample, the row picked by the scalar offset
+  // (rows are S * 8 bytes apart: 9 S * 8 < 2^31 is checked by ed_batch_create)
+  const __amdgpu_buffer_rsrc_t rc = ed_rsrc(consts + s0, (int32_t)((8 * S + blk_samples) * 8));
+  const __amdgpu_buffer_rsrc_t rf = ed_rsrc(cflags + s0, (int32_t)((2 * S + blk_samples) * 4));
+  const int32_t rowb = (int32_t)(S * 8);
+  double pa1[3], pa2[3];
+  int pcf[3];
 #pragma unroll
-    for (int st = 0; st < 3; ++st) {
-      pa1[st] = consts[(st * 3 + 0) * S + s];
-      pa2[st] = consts[(st * 3 + 1) * S + s];
-      pcf[st] = cflags[st * S + s];
-    }
+  for (int st = 0; st < 3; ++st) {
+    pa1[st] = ed_buf_f64(rc, l8, (st * 3 + 0) * rowb);
+    pa2[st] = ed_buf_f64(rc, l8, (st * 3 + 1) * rowb);
+    pcf[st] = __builtin_amdgcn_raw_buffer_load_b32(rf, l4, st * (rowb / 2), 0);
   }
   if (tid == 0) { n_front = 0; n_back = 0; }
   {
@@ -281,12 +308,9 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
     bool cold_any = false;
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
-      double x = 1.0, y = 1.0;
-      if (live) {
-        x = pa1[st] + (double)obs;                       // src/CNV_estimate.cpp:49
-        y = (pa2[st] + (double)tot) - (double)obs;
-        nflag += pcf[st] * (empty ? 2 : 1);
-      }
+      const double x = pa1[st] + (double)obs;                       // src/CNV_estimate.cpp:49
+      const double y = (pa2[st] + (double)tot) - (double)obs;
+      nflag += live ? pcf[st] * (empty ? 2 : 1) : 0;
       const bool pos = (x > 0.0 && y > 0.0);
       const double mx = (x > y ? x : y);
       const double mn = (x < y ? x : y);
@@ -357,21 +381,21 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
     }
   }
   // the per-sample constants of phase 3, requested before the barrier: their latency is spent waiting for the other waves
-  double pc[3] = {0.0, 0.0, 0.0};
-  if (live) {
+  double pc[3];
 #pragma unroll
-    for (int st = 0; st < 3; ++st) pc[st] = consts[(st * 3 + 2) * S + s];
-  }
+  for (int st = 0; st < 3; ++st) pc[st] = ed_buf_f64(rc, l8, (st * 3 + 2) * rowb);
   __syncthreads();
   // ---- phase 3: gather, subtract the per-sample constant, store ----
   if (live) {
+    // the three rows [e][st][s0 ..] of this exon: one resource, rows S * 8 bytes apart
+    const __amdgpu_buffer_rsrc_t rl = ed_rsrc(loglik + (e_first * 3 * S + s0), (int32_t)((2 * S + blk_samples) * 8));
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
       const double c = pc[st];
       const int sl = slot[st];
       if (sl == -3) continue;                       // k_emit_cold writes this value
       const double v = t_a[sl < 0 ? 0 : sl];
-      __builtin_nontemporal_store((sl == -2 ? c : v) - c, &loglik[(e_first * 3 + st) * S + s]);
+      ed_buf_store_f64_nt(rl, l8, st * rowb, (sl == -2 ? c : v) - c);
     }
   }
   if (nflag) atomicAdd(nerr, (unsigned long long)nflag);
