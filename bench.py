@@ -174,12 +174,22 @@ def main():
                     "the emissions of the following groups (the lone-batch schedule); -1 = the library's default")
     ap.add_argument("--fit-priority", type=int, default=0, help="priority of the stream the fit runs on in pipelined mode (0 = normal; -1 = high: "
                     "the fit then pushes into the running emission launch and costs it more than it saves, 12.2 against 11.5 ms)")
+    ap.add_argument("--hw-queues", type=int, default=6, help="GPU_MAX_HW_QUEUES for this process unless the environment already sets it "
+                    "(0 = leave the runtime's default, 4)")
     ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
     args = ap.parse_args()
+
+    # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and which streams share
+    # a queue decides how the pipelined schedule unfolds.  With 6, the fit of the next batch is served in
+    # the middle of this batch's emission launch and the chains ride under the start of the next one: 0.6 ms between
+    # emission launches instead of 2.3, 5-6 % more exons*samples/s (measured on three boxes; 4, 5, 7, 8, 16: slower).
+    # Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
+    if args.hw_queues > 0:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues))
 
     import torch
     import torch.distributed as dist
@@ -332,6 +342,17 @@ def main():
             stage_ms[k] += v
     assert n_timed == args.steps, (n_timed, args.steps)
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
+    # (outside the timed region) the emission launch with the GPU to itself: one batch, given phi, nothing queued on
+    # other streams -- what the kernel takes when it does not host the next batch's fit and the previous batch's chains
+    alone_ms = None
+    if plain and not args.fused and args.pipeline and rank == 0:
+        bb = batches[0]
+        bb.enable_timing(True)
+        for _ in range(3):
+            bb.run(test, ref, phi_fit[0] if args.fit else phi, p_fit[0] if args.fit else p, 1.0, stream=stream)
+            torch.cuda.synchronize()
+            bb.wait()
+        alone_ms = bb.stage_ms()["emissions"]
 
     if rank == 0:
         kernel = "k_emit_viterbi" if args.fused else ("k_emit_batch" if plain else "k_emit_bins")
@@ -368,6 +389,8 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * E * S / n_launch,
                          "kernel_cells_per_s": kernel_cells_per_s,
                          "algorithmic_bytes_per_cell_with_likelihood_matrix": 33,
+                         "kernel_ms_alone": alone_ms,
+                         "frac_alone": (ALGO_BYTES_PER_CELL * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "valu": pmc if pmc else why_not,
                          "note": "FP64-VALU-bound kernel (no MFMA applies; SURVEY.md 0.5): the HBM roofline is the formal denominator, "
                                  "roofline.valu (rocprofv3 PMC passes taken on this very build of the kernels, else withheld) the meaningful "
