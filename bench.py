@@ -174,6 +174,8 @@ def main():
                     "the emissions of the following groups (the lone-batch schedule); -1 = the library's default")
     ap.add_argument("--fit-priority", type=int, default=0, help="priority of the stream the fit runs on in pipelined mode (0 = normal; -1 = high: "
                     "the fit then pushes into the running emission launch and costs it more than it saves, 12.2 against 11.5 ms)")
+    ap.add_argument("--kernel-alone", type=int, default=1, help="1 (default): after the timed region, time three emission launches with the GPU to "
+                    "themselves (roofline.kernel_ms_alone); 0: skip (profiling passes, so that per-kernel averages contain the live launches only)")
     ap.add_argument("--hw-queues", type=int, default=6, help="GPU_MAX_HW_QUEUES for this process unless the environment already sets it "
                     "(0 = leave the runtime's default, 4)")
     ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
@@ -345,7 +347,7 @@ def main():
     # (outside the timed region) the emission launch with the GPU to itself: one batch, given phi, nothing queued on
     # other streams -- what the kernel takes when it does not host the next batch's fit and the previous batch's chains
     alone_ms = None
-    if plain and not args.fused and args.pipeline and rank == 0:
+    if plain and not args.fused and args.pipeline and rank == 0 and args.kernel_alone:
         bb = batches[0]
         bb.enable_timing(True)
         for _ in range(3):
