@@ -204,14 +204,28 @@ def main():
     backend = os.environ.get("ED_BENCH_BACKEND", "nccl")
     if os.environ.get("ED_BENCH_SHARE_GPU") == "1":
         local_rank = 0
-    if world > 1:
+    # ED_BENCH_FORCE_PG=1: a process group of ONE rank on a 1-GPU box -- RCCL's streams and queue usage without a second GPU
+    use_pg = world > 1 or os.environ.get("ED_BENCH_FORCE_PG") == "1"
+
+    def init_pg():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+
+    # The process group is initialised AFTER the pipeline's streams have been used once (below): hardware queues are handed to
+    # streams in order of first use, and RCCL takes one when it starts -- which would shift the stream-to-queue mapping of
+    # DESIGN.md 4.10 (vi) by one and cost its 5-6 %.  Only a never-built tree needs the group first (ranks wait for rank 0's build).
+    from exomedepth_amd import _build as _build0
+    pg_early = use_pg and (not os.path.exists(_build0.LIB) or os.environ.get("ED_BENCH_PG_FIRST") == "1")
+    if pg_early:
+        init_pg()
     cdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")   # device of the collectives
     if args.gpus != world:
         if rank == 0:
@@ -229,7 +243,7 @@ def main():
     from exomedepth_amd import _build, dist as eddist
     if not os.path.exists(_build.LIB) and rank == 0:   # never-built tree: compile the HIP library (there is no other path)
         _build.build()
-    if world > 1:
+    if pg_early:
         dist.barrier()
     from exomedepth_amd import synth
 
@@ -293,13 +307,13 @@ def main():
         else:
             b.run(test, ref, phi, p, 1.0, stream=stream)
 
-    def finish():
+    def finish(collect=True):
         """final gather of the compact call tables (the path's only collective); every batch in flight is drained"""
         for j, b in enumerate(batches):
             if j < step_no[0] and j != (step_no[0] - 1) % n_batches:
                 b.n_calls()                               # (a batch object that has run: wait for its tail)
         last = batches[(step_no[0] - 1) % n_batches]
-        if world > 1:
+        if world > 1 and collect:
             # rows straight from the device table when the collectives run on the GPU (RCCL); through the host for gloo
             t = eddist.device_call_table(last) if cdev.type == "cuda" else eddist.calls_to_tensor(last.calls(), cdev)
             g = eddist.gather_call_tables(t, rank * S)
@@ -307,9 +321,13 @@ def main():
         return last.n_calls()
 
     for _ in range(n_batches):        # setup: every batch object allocates its working set (likelihood matrix, fit workspace) once
-        step()
-    finish()
+        step()                        # ... and every stream of the pipeline is used for the first time
+    finish(collect=pg_early)
     torch.cuda.synchronize()
+    if use_pg and not pg_early:
+        init_pg()
+    if use_pg:
+        dist.barrier()
     step_no[0] = 0
     for _ in range(args.warmup):
         step()
@@ -317,17 +335,17 @@ def main():
     torch.cuda.synchronize()
     for b in batches:
         b.enable_timing(True)     # (resets the stage-time sums: the warm-up is not part of them)
-    if world > 1:
+    if use_pg:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     n_calls = finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
