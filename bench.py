@@ -176,6 +176,7 @@ def main():
                     "the fit then pushes into the running emission launch and costs it more than it saves, 12.2 against 11.5 ms)")
     ap.add_argument("--kernel-alone", type=int, default=1, help="1 (default): after the timed region, time three emission launches with the GPU to "
                     "themselves (roofline.kernel_ms_alone); 0: skip (profiling passes, so that per-kernel averages contain the live launches only)")
+    ap.add_argument("--pretouch-streams", type=int, default=0, help="(diagnostic) use that many unrelated streams before the pipeline's streams are first used")
     ap.add_argument("--hw-queues", type=int, default=6, help="GPU_MAX_HW_QUEUES for this process unless the environment already sets it "
                     "(0 = leave the runtime's default, 4)")
     ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
@@ -253,6 +254,12 @@ def main():
     test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=20250620 + 3 + 1000 * rank, mean_depth=args.depth)
     torch.cuda.synchronize()
 
+    # (diagnostic) other streams used before the pipeline's: shifts the stream-to-hardware-queue mapping by that many
+    _pre_streams = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.pretouch_streams))]
+    for _s in _pre_streams:
+        with torch.cuda.stream(_s):
+            torch.zeros(8, device=dev).add_(1)
+    torch.cuda.synchronize()
     plan = ed.Plan(chrom_off, start, end, 1e-4, 50000.0, device=local_rank)
     plain = args.cov == 0 and args.phi_bins == 1
     # Two-deep pipeline (default): two batch objects used alternately.  All emissions go to ONE stream, back to back; the
