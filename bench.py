@@ -177,8 +177,19 @@ def main():
     ap.add_argument("--kernel-alone", type=int, default=1, help="1 (default): after the timed region, time three emission launches with the GPU to "
                     "themselves (roofline.kernel_ms_alone); 0: skip (profiling passes, so that per-kernel averages contain the live launches only)")
     ap.add_argument("--pretouch-streams", type=int, default=0, help="(diagnostic) use that many unrelated streams before the pipeline's streams are first used")
-    ap.add_argument("--hw-queues", type=int, default=6, help="GPU_MAX_HW_QUEUES for this process unless the environment already sets it "
-                    "(0 = leave the runtime's default, 4)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="(diagnostic) GPU_MAX_HW_QUEUES for this process unless the environment already sets it "
+                    "(0, default = leave the runtime alone: the cohort pipeline gives its streams hardware queues of their own)")
+    ap.add_argument("--driver", default="cohort", choices=["cohort", "python"], help="cohort (default): the steps are submitted to the "
+                    "library's cohort pipeline (ed_cohort_*: its own streams, batch rotation, event-ordered stages); python: round 2's "
+                    "orchestration of two batch objects with torch streams (kept for comparison)")
+    ap.add_argument("--split", type=float, default=-1.0, help="cohort driver: fraction of a slab's emission launch after which the next slab's fit "
+                    "is issued (-1 = the library's default)")
+    ap.add_argument("--own-queues", type=int, default=-1, help="cohort driver: 1 = every stream of the pipeline gets a hardware queue of its own, "
+                    "0 = ordinary streams (-1 = the library's default, 1)")
+    ap.add_argument("--stage-inputs", type=int, default=0, help="1: additionally time the same steps with the counts uploaded from pinned host "
+                    "memory for every slab (copy stream, double-buffered device slabs): reported as value_with_h2d, never as value")
+    ap.add_argument("--wire", type=int, default=2, help="--stage-inputs: bytes per count on the link (2 = uint16 widened on the device, 4 = int32)")
+    ap.add_argument("--verify-columns", type=int, default=4, help="columns of the last slabs checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
@@ -262,64 +273,112 @@ def main():
     torch.cuda.synchronize()
     plan = ed.Plan(chrom_off, start, end, 1e-4, 50000.0, device=local_rank)
     plain = args.cov == 0 and args.phi_bins == 1
-    # Two-deep pipeline (default): two batch objects used alternately.  All emissions go to ONE stream, back to back; the
-    # dispersion fit of the next batch is issued on a second stream and the Viterbi tail / call table of the previous batch
-    # finish on streams of its own (ed_batch_set_async_tail), so both execute underneath the VALU-bound emission kernels.
-    # Every step still does the whole path on its batch; --pipeline 0 runs the steps strictly one after the other.
-    n_batches = max(2, args.batches_in_flight) if (args.pipeline and plain and not args.fused) else 1
-    batches = [ed.Batch(plan, S) for _ in range(n_batches)]
-    for b in batches:
-        b.enable_timing(True)
-        b.set_fused(bool(args.fused))
-        b.keep_loglik(bool(args.keep_loglik))
-        b.set_async_tail(n_batches >= 2)
-        if n_batches >= 2 and args.viterbi_overlap >= 0:
-            b.set_viterbi_overlap(bool(args.viterbi_overlap))
-    batch = batches[0]
-    main_stream = torch.cuda.current_stream()
-    fit_stream = torch.cuda.Stream(device=dev, priority=args.fit_priority) if n_batches >= 2 else main_stream
-    stream = main_stream.cuda_stream
-    phi_fit = [torch.empty(S, dtype=torch.float64, device=dev) for _ in batches]
-    p_fit = [torch.empty(S, dtype=torch.float64, device=dev) for _ in batches]
-    phib_fit = torch.empty((max(args.phi_bins, 1), S), dtype=torch.float64, device=dev)
-    Xcov = (torch.rand((E, max(args.cov, 1)), dtype=torch.float64, device=dev) - 0.5) * 0.4 if args.cov > 0 else None
-    beta_fit = torch.empty((max(args.cov, 0) + 1, S), dtype=torch.float64, device=dev)
-    edges_fit = torch.empty((max(args.phi_bins, 1) + 1, S), dtype=torch.float64, device=dev)
+    use_cohort = args.driver == "cohort" and plain and not args.fused
     step_no = [0]
-    emitted = [None] * n_batches     # per batch object: event on the main stream after its last run's emission launches
+    if use_cohort:
+        # The library's cohort pipeline: every step is ONE submission (ed_cohort_submit); the library owns the streams, rotates
+        # its batch objects and orders the stages of consecutive slabs with events (csrc/edcohort.inc).
+        # --pipeline 0: one slab in flight, i.e. the steps strictly one after the other.
+        n_batches = max(2, args.batches_in_flight) if args.pipeline else 1
+        opts = {"timing": 1}
+        if args.viterbi_overlap >= 0:
+            opts["viterbi_overlap"] = args.viterbi_overlap
+        if args.split >= 0:
+            opts["split"] = args.split
+        if args.own_queues >= 0:
+            opts["own_queues"] = args.own_queues
+        co = ed.Cohort(plan, S, n_batches, **opts)
+        batches = []
+        last_ticket = [-1]
 
-    def step():
-        k = step_no[0] % n_batches
-        step_no[0] += 1
-        b = batches[k]
-        if args.cov > 0:
-            b.fit_cov(test, ref, Xcov, beta_fit, phi_fit[0], stream=stream)
-            b.run_cov(test, ref, Xcov, beta_fit, phi_fit[0], 1.0, stream=stream)
-        elif args.phi_bins > 1:
-            b.fit_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit[0], stream=stream)
-            b.run_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit[0], 1.0, stream=stream)
-        elif args.fit:
-            if fit_stream is not main_stream and emitted[k] is not None:
-                # this fit overwrites (phi, expected) of the batch object's previous run, two steps back: not before that
-                # run's emission kernels -- which read the per-sample constants made from them -- are through.  (It also
-                # keeps the fit stream from running more than one batch ahead: fit(N+2) executes underneath emissions(N+1).)
-                fit_stream.wait_event(emitted[k])
-            b.fit(test, ref, phi_fit[k], p_fit[k], stream=fit_stream.cuda_stream)
-            if fit_stream is not main_stream:
-                main_stream.wait_stream(fit_stream)      # the emissions of this batch need its (phi, expected)
-            b.run(test, ref, phi_fit[k], p_fit[k], 1.0, stream=stream)
-            if fit_stream is not main_stream:
-                emitted[k] = torch.cuda.Event()
-                emitted[k].record(main_stream)
-        else:
-            b.run(test, ref, phi, p, 1.0, stream=stream)
+        def step():
+            step_no[0] += 1
+            if args.fit:
+                last_ticket[0] = co.submit(test, ref, n_samples=S)
+            else:
+                last_ticket[0] = co.submit(test, ref, phi=phi, expected=p, n_samples=S)
+
+        def last_batch():
+            b, _, _ = co.batch(last_ticket[0])
+            b.n_samples = S
+            return b
+
+        def drain():
+            co.drain()
+
+        def stage_totals():
+            return [co.stage_ms_total()]
+
+        def reset_timing():
+            co.set_option("timing", 1)
+
+        n_launch_of = lambda: co.n_emit_launches
+    else:
+        # round 2's driver: two batch objects used alternately, orchestrated here with torch streams
+        n_batches = max(2, args.batches_in_flight) if (args.pipeline and plain and not args.fused) else 1
+        batches = [ed.Batch(plan, S) for _ in range(n_batches)]
+        for b in batches:
+            b.enable_timing(True)
+            b.set_fused(bool(args.fused))
+            b.keep_loglik(bool(args.keep_loglik))
+            b.set_async_tail(n_batches >= 2)
+            if n_batches >= 2 and args.viterbi_overlap >= 0:
+                b.set_viterbi_overlap(bool(args.viterbi_overlap))
+        main_stream = torch.cuda.current_stream()
+        fit_stream = torch.cuda.Stream(device=dev, priority=args.fit_priority) if n_batches >= 2 else main_stream
+        stream = main_stream.cuda_stream
+        phi_fit = [torch.empty(S, dtype=torch.float64, device=dev) for _ in batches]
+        p_fit = [torch.empty(S, dtype=torch.float64, device=dev) for _ in batches]
+        phib_fit = torch.empty((max(args.phi_bins, 1), S), dtype=torch.float64, device=dev)
+        Xcov = (torch.rand((E, max(args.cov, 1)), dtype=torch.float64, device=dev) - 0.5) * 0.4 if args.cov > 0 else None
+        beta_fit = torch.empty((max(args.cov, 0) + 1, S), dtype=torch.float64, device=dev)
+        edges_fit = torch.empty((max(args.phi_bins, 1) + 1, S), dtype=torch.float64, device=dev)
+        emitted = [None] * n_batches     # per batch object: event on the main stream after its last run's emission launches
+
+        def step():
+            k = step_no[0] % n_batches
+            step_no[0] += 1
+            b = batches[k]
+            if args.cov > 0:
+                b.fit_cov(test, ref, Xcov, beta_fit, phi_fit[0], stream=stream)
+                b.run_cov(test, ref, Xcov, beta_fit, phi_fit[0], 1.0, stream=stream)
+            elif args.phi_bins > 1:
+                b.fit_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit[0], stream=stream)
+                b.run_bins(test, ref, args.phi_bins, phib_fit, edges_fit, p_fit[0], 1.0, stream=stream)
+            elif args.fit:
+                if fit_stream is not main_stream and emitted[k] is not None:
+                    fit_stream.wait_event(emitted[k])   # (phi, expected) of this batch object's previous run are still being read
+                b.fit(test, ref, phi_fit[k], p_fit[k], stream=fit_stream.cuda_stream)
+                if fit_stream is not main_stream:
+                    main_stream.wait_stream(fit_stream)      # the emissions of this batch need its (phi, expected)
+                b.run(test, ref, phi_fit[k], p_fit[k], 1.0, stream=stream)
+                if fit_stream is not main_stream:
+                    emitted[k] = torch.cuda.Event()
+                    emitted[k].record(main_stream)
+            else:
+                b.run(test, ref, phi, p, 1.0, stream=stream)
+
+        def last_batch():
+            return batches[(step_no[0] - 1) % n_batches]
+
+        def drain():
+            for j, b in enumerate(batches):
+                if j < step_no[0]:
+                    b.n_calls()                               # (a batch object that has run: wait for its tail)
+
+        def stage_totals():
+            return [b.stage_ms_total() for b in batches]
+
+        def reset_timing():
+            for b in batches:
+                b.enable_timing(True)
+
+        n_launch_of = lambda: batches[0].n_emit_launches
 
     def finish(collect=True):
-        """final gather of the compact call tables (the path's only collective); every batch in flight is drained"""
-        for j, b in enumerate(batches):
-            if j < step_no[0] and j != (step_no[0] - 1) % n_batches:
-                b.n_calls()                               # (a batch object that has run: wait for its tail)
-        last = batches[(step_no[0] - 1) % n_batches]
+        """final gather of the compact call tables (the path's only collective); every slab in flight is drained"""
+        drain()
+        last = last_batch()
         if world > 1 and collect:
             # rows straight from the device table when the collectives run on the GPU (RCCL); through the host for gloo
             t = eddist.device_call_table(last) if cdev.type == "cuda" else eddist.calls_to_tensor(last.calls(), cdev)
@@ -340,8 +399,7 @@ def main():
         step()
     finish()
     torch.cuda.synchronize()
-    for b in batches:
-        b.enable_timing(True)     # (resets the stage-time sums: the warm-up is not part of them)
+    reset_timing()                    # (resets the stage-time sums: the warm-up is not part of them)
     if use_pg:
         dist.barrier()
     t0 = time.perf_counter()
@@ -362,30 +420,38 @@ def main():
     # per-stage device times: HIP events recorded by the library on the streams the kernels run on, summed over the timed steps
     stage_ms = {k: 0.0 for k in ed.Batch.STAGES}
     n_timed = 0
-    for b in batches:
-        tot, nr, nf = b.stage_ms_total()
+    for tot, nr, nf in stage_totals():
         n_timed += nr
         for k, v in tot.items():
             stage_ms[k] += v
     assert n_timed == args.steps, (n_timed, args.steps)
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
-    # (outside the timed region) the emission launch with the GPU to itself: one batch, given phi, nothing queued on
-    # other streams -- what the kernel takes when it does not host the next batch's fit and the previous batch's chains
+    n_launch = max(1, n_launch_of())   # emission launches per step
+    # (outside the timed region) the emission launches with the GPU to themselves: one slab, given phi, nothing queued on
+    # other streams -- what the kernel takes when it does not host the next slab's fit and the previous slab's chains
     alone_ms = None
     if plain and not args.fused and args.pipeline and rank == 0 and args.kernel_alone:
-        bb = batches[0]
-        bb.enable_timing(True)
-        for _ in range(3):
-            bb.run(test, ref, phi_fit[0] if args.fit else phi, p_fit[0] if args.fit else p, 1.0, stream=stream)
-            torch.cuda.synchronize()
-            bb.wait()
-        alone_ms = bb.stage_ms()["emissions"]
+        if use_cohort:
+            b_last, pp, pe = co.batch(last_ticket[0])
+            par = (ed.api._RawDevice(pp), ed.api._RawDevice(pe)) if args.fit else (phi, p)
+            reset_timing()
+            for _ in range(3):
+                co.submit(test, ref, phi=par[0], expected=par[1], n_samples=S)
+                co.drain()
+            alone_ms = co.stage_ms_total()[0]["emissions"] / 3.0
+        else:
+            bb = batches[0]
+            bb.enable_timing(True)
+            for _ in range(3):
+                bb.run(test, ref, phi_fit[0] if args.fit else phi, p_fit[0] if args.fit else p, 1.0, stream=stream)
+                torch.cuda.synchronize()
+                bb.wait()
+            alone_ms = bb.stage_ms()["emissions"]
 
     if rank == 0:
         kernel = "k_emit_viterbi" if args.fused else ("k_emit_batch" if plain else "k_emit_bins")
         t_emit = stage_ms["emissions"] * 1e-3
         achieved = ALGO_BYTES_PER_CELL * E * S / t_emit / 1e9 if t_emit > 0 else 0.0
-        n_launch = max(1, batch.n_emit_launches)   # one emission launch per overlap group of chromosomes (+ short head launches)
         kernel_cells_per_s = (E * S / t_emit) if t_emit else 0.0
         meta, why_not = matching_profile()
         if meta:
@@ -406,7 +472,7 @@ def main():
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
                        "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
-                       "batches_in_flight": n_batches,
+                       "batches_in_flight": n_batches, "driver": ("cohort (ed_cohort_submit: the library's own streams and batch rotation)" if use_cohort else "python (torch streams)"),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered to rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -442,6 +508,8 @@ def main():
         print(json.dumps(out))
     for b in batches:
         b.close()
+    if use_cohort:
+        co.close()
     plan.close()
     if world > 1:
         dist.destroy_process_group()

@@ -7,7 +7,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedcore.so")
 SOURCES = ["edcore.hip"]
-DEPS = ["edcore.hip", "edfit_hist.inc", "edrefset.inc", "edfused.inc", "edbins.inc", "edcov.inc", "ed_sf_dev.hpp", "ed_pmath.h", "ed_fit_dev.hpp", "../../include/exomedepth_amd.h"]
+def _deps():
+    """every file the library is built from: all of csrc/ (sources, .inc, headers -- generated tables included) + the C-ABI header"""
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".inc", ".hpp", ".h")))
+    return names + ["../../include/exomedepth_amd.h"]
+
+
+DEPS = _deps()
 # -ffp-contract=off is part of the numerical contract (see csrc/ed_pmath.h): no implicit fma.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fvisibility=hidden"]

@@ -90,6 +90,23 @@ SYMBOLS = [
     ("ed_refset_thin_positions", C.c_int, [_i64, _i64, _vp, _i64, C.POINTER(_i64)]),
     ("ed_get_power_betabinom", C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
     ("ed_get_power_betabinom_mode", C.c_int, [_i64, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("ed_cohort_create", C.c_int, [C.POINTER(_vp), _vp, _i64, C.c_int]),
+    ("ed_cohort_destroy", None, [_vp]),
+    ("ed_cohort_set_option", C.c_int, [_vp, C.c_char_p, _dbl]),
+    ("ed_cohort_submit", C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _dbl, _vp, C.POINTER(_i64)]),
+    ("ed_cohort_batch", C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    ("ed_cohort_wait", C.c_int, [_vp, _i64]),
+    ("ed_cohort_drain", C.c_int, [_vp]),
+    ("ed_cohort_stream", _vp, [_vp]),
+    ("ed_cohort_stage_ms_total", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
+    ("ed_cohort_n_emit_launches", C.c_int, [_vp]),
+    ("ed_cohort_submit_host", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _i64, _vp, _vp, _dbl, C.POINTER(_i64)]),
+    ("ed_cohort_ingest_stats", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("ed_host_alloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    ("ed_host_free", C.c_int, [_vp]),
+    ("ed_cohort_run_host", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, C.POINTER(_i64)]),
+    ("ed_cohort_copy_calls", C.c_int, [_vp, _vp, _vp, _i64]),
+    ("ed_cohort_run_status", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     ("ed_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
     ("ed_free", C.c_int, [_vp]),
     ("ed_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t]),

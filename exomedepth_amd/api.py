@@ -138,10 +138,17 @@ class DeviceArray:
             pass
 
 
+class _RawDevice:
+    """a bare device pointer owned by somebody else (e.g. a cohort slot's fitted parameters)"""
+
+    def __init__(self, ptr):
+        self.ptr = C.c_void_p(ptr)
+
+
 def _device_pointer(x, dtype, keep):
     """Return a c_void_p for x: a torch CUDA tensor (used in place), a DeviceArray, or host data
     (uploaded; the temporary is appended to `keep`)."""
-    if isinstance(x, DeviceArray):
+    if isinstance(x, (DeviceArray, _RawDevice)):
         return x.ptr
     if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
         if not x.is_cuda:
@@ -201,10 +208,20 @@ class Batch:
         self._keep_fit = []   # ... for the last fit*() (outputs may be read by the caller after the call)
         check(lib().ed_batch_create(C.byref(self.handle), plan.handle, self.n_samples))
 
+    _owned = True
+
+    @classmethod
+    def _view(cls, plan, n_samples, handle):
+        """a Batch interface on a batch object owned by somebody else (a Cohort's slot): close() leaves it alone"""
+        b = cls.__new__(cls)
+        b.plan, b.n_samples, b.handle = plan, int(n_samples), C.c_void_p(handle)
+        b._keep_run, b._keep_fit, b._owned = [], [], False
+        return b
+
     def close(self):
-        if self.handle:
+        if self.handle and self._owned:
             lib().ed_batch_destroy(self.handle)
-            self.handle = C.c_void_p()
+        self.handle = C.c_void_p()
         self._keep_run = []
         self._keep_fit = []
 
@@ -425,6 +442,179 @@ class Batch:
         ms = (C.c_float * 5)()
         check(lib().ed_batch_stage_ms(self.handle, ms))
         return dict(zip(self.STAGES, [float(v) for v in ms]))
+
+
+class PinnedArray:
+    """A numpy array in pinned host memory (ed_host_alloc): the DMA engine reads it in place, no staging copy."""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(int(x) for x in np.atleast_1d(shape))
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = C.c_void_p()
+        check(lib().ed_host_alloc(C.byref(self.ptr), self.nbytes))
+        buf = (C.c_char * max(self.nbytes, 1)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().ed_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Cohort:
+    """Slabs of a cohort through the library's pipeline (ed_cohort_*): the loop of reference vignette/vignette.Rnw:390-431
+    -- new('ExomeDepth') + CallCNVs() per sample -- for slabs of samples, on streams the library owns.
+
+    submit() / submit_host() return a ticket; batch(ticket) gives a Batch view holding that slab's results (valid until
+    `slabs_in_flight` further slabs have been submitted).  run_host() does a whole host-resident cohort."""
+
+    STAGES = Batch.STAGES
+
+    def __init__(self, plan, slab_samples, slabs_in_flight=2, **options):
+        self.plan = plan
+        self.slab_samples = int(slab_samples)
+        self.slabs_in_flight = int(slabs_in_flight)
+        self.handle = C.c_void_p()
+        self._keep = {}
+        check(lib().ed_cohort_create(C.byref(self.handle), plan.handle, self.slab_samples, self.slabs_in_flight))
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        check(lib().ed_cohort_set_option(self.handle, name.encode(), float(value)))
+
+    def close(self):
+        if self.handle:
+            lib().ed_cohort_destroy(self.handle)
+            self.handle = C.c_void_p()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().ed_cohort_stream(self.handle)
+
+    @property
+    def n_emit_launches(self):
+        return int(lib().ed_cohort_n_emit_launches(self.handle))
+
+    def submit(self, test, ref, phi=None, expected=None, mixture=1.0, ready_stream=None, n_samples=None):
+        """one slab, counts on the device: (n_exons, n) int32 torch CUDA tensors / DeviceArrays (host arrays are uploaded
+        synchronously first -- use submit_host for the staged path).  phi / expected: device float64[n] or None (fit)."""
+        keep = []
+        if n_samples is None:
+            n_samples = int(test.shape[1])
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi, np.float64, keep) if phi is not None else None
+        pe = _device_pointer(expected, np.float64, keep) if expected is not None else None
+        t = C.c_int64(-1)
+        check(lib().ed_cohort_submit(self.handle, pt, pr, int(n_samples), pp, pe, float(mixture), C.c_void_p(ready_stream or 0), C.byref(t)))
+        # the slab's counts are read until its results have been collected (the call decoration): keep them alive that long
+        self._keep[t.value % self.slabs_in_flight] = keep + [test, ref, phi, expected]
+        return t.value
+
+    def submit_host(self, test, ref, layout, phi=None, expected=None, mixture=1.0, n_samples=None, row_stride=None):
+        """one slab from host memory.  layout 0: (n_exons, n) sample-minor arrays (or a window of the first n columns of a wider
+        matrix: pass n_samples and row_stride); layout 1: R's column-major n_exons x n matrix, i.e. a C-contiguous (n, n_exons)
+        array.  dtype int32 or uint16 (the 16-bit wire format).  numpy arrays or PinnedArray.array views."""
+        test, ref = np.asarray(test), np.asarray(ref)
+        if test.dtype != ref.dtype or test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
+            raise ValueError("test and ref must both be int32 or both uint16")
+        wire = test.dtype.itemsize
+        if n_samples is None:
+            n_samples = int(test.shape[1] if layout == 0 else test.shape[0])
+        if row_stride is None:
+            row_stride = int(test.strides[0] // wire) if layout == 0 else 0
+        keep = []
+        pp = _device_pointer(phi, np.float64, keep) if phi is not None else None
+        pe = _device_pointer(expected, np.float64, keep) if expected is not None else None
+        t = C.c_int64(-1)
+        check(lib().ed_cohort_submit_host(self.handle, C.c_void_p(test.ctypes.data), C.c_void_p(ref.ctypes.data), int(n_samples),
+                                          int(layout), int(wire), int(row_stride), pp, pe, float(mixture), C.byref(t)))
+        self._keep[t.value % self.slabs_in_flight] = keep + [test, ref]
+        return t.value
+
+    def batch(self, ticket):
+        """(Batch view, device pointer of phi, device pointer of expected) of a ticket"""
+        h, pp, pe = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().ed_cohort_batch(self.handle, int(ticket), C.byref(h), C.byref(pp), C.byref(pe)))
+        n = C.c_int64(0)
+        b = Batch._view(self.plan, 0, h.value)
+        return b, pp.value, pe.value
+
+    def results(self, ticket, n_samples, path=False, loglik=False, info=True):
+        """host copies of a ticket's results: dict(calls, info, phi, expected[, path][, loglik])"""
+        b, pp, pe = self.batch(ticket)
+        b.n_samples = int(n_samples)
+        out = {"calls": b.calls()}
+        if info:
+            out["info"] = b.call_info()
+        phi = np.empty(n_samples); exp = np.empty(n_samples)
+        check(lib().ed_memcpy_d2h(_ptr(phi), C.c_void_p(pp), phi.nbytes))
+        check(lib().ed_memcpy_d2h(_ptr(exp), C.c_void_p(pe), exp.nbytes))
+        out["phi"], out["expected"] = phi, exp
+        if path:
+            out["path"] = b.path()
+        if loglik:
+            out["loglik"] = b.loglik()
+        return out
+
+    def wait(self, ticket):
+        check(lib().ed_cohort_wait(self.handle, int(ticket)))
+
+    def drain(self):
+        check(lib().ed_cohort_drain(self.handle))
+
+    def stage_ms_total(self):
+        ms = (C.c_double * 5)()
+        nr, nf = C.c_int64(0), C.c_int64(0)
+        check(lib().ed_cohort_stage_ms_total(self.handle, ms, C.byref(nr), C.byref(nf)))
+        return dict(zip(self.STAGES, [float(v) for v in ms])), nr.value, nf.value
+
+    def ingest_stats(self):
+        b, s = C.c_double(0), C.c_double(0)
+        check(lib().ed_cohort_ingest_stats(self.handle, C.byref(b), C.byref(s)))
+        return b.value, s.value
+
+    def run_host(self, test, ref, layout, phi=None, expected=None, mixture=1.0, want_path=False):
+        """CallCNVs for a whole host-resident cohort (ed_cohort_run_host).  layout 0: (n_exons, S) arrays; layout 1: (S, n_exons)
+        arrays (R's column-major n_exons x S matrix).  Returns dict(calls, info, phi, expected, n_unconverged, n_gsl_errors[, path])."""
+        test, ref = np.ascontiguousarray(test), np.ascontiguousarray(ref)
+        if test.dtype != ref.dtype or test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
+            raise ValueError("test and ref must both be int32 or both uint16")
+        S = int(test.shape[1] if layout == 0 else test.shape[0])
+        E = self.plan.n_exons
+        ph = _f64(phi) if phi is not None else None
+        ex = _f64(expected) if expected is not None else None
+        phi_out, exp_out = np.empty(S), np.empty(S)
+        path = np.empty((E, S) if layout == 0 else (S, E), dtype=np.uint8) if want_path else None
+        n = C.c_int64(0)
+        check(lib().ed_cohort_run_host(self.handle, C.c_void_p(test.ctypes.data), C.c_void_p(ref.ctypes.data), S, int(layout),
+                                       int(test.dtype.itemsize), _ptr(ph) if ph is not None else None, _ptr(ex) if ex is not None else None,
+                                       float(mixture), _ptr(phi_out), _ptr(exp_out), _ptr(path) if path is not None else None, C.byref(n)))
+        calls = np.zeros(n.value, dtype=CALL_DTYPE)
+        info = np.zeros(n.value, dtype=CALL_INFO_DTYPE)
+        check(lib().ed_cohort_copy_calls(self.handle, _ptr(calls), _ptr(info), n.value))
+        nu, ne = C.c_int64(0), C.c_int64(0)
+        check(lib().ed_cohort_run_status(self.handle, C.byref(nu), C.byref(ne)))
+        out = {"calls": calls, "info": info, "phi": phi_out, "expected": exp_out, "n_unconverged": nu.value, "n_gsl_errors": ne.value}
+        if want_path:
+            out["path"] = path
+        return out
 
 
 # ---------------------------------------------------------------------------------------------

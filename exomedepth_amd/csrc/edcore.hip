@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1572,6 +1573,8 @@ struct ed_batch {
   int64_t* d_total = nullptr;
   unsigned long long* d_nerr = nullptr;
   ed_call* d_calls = nullptr;
+  ed_call_info* d_info = nullptr;    // decoration of the call table (grown on demand: hipFree would synchronise the device
+  int64_t info_cap = 0;              // and with it every other batch of a pipeline)
   struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
   int64_t calls_cap = 0;
   hipStream_t stream = nullptr;         // where the results of the last run become available: the caller's stream, or `fin`
@@ -1581,7 +1584,15 @@ struct ed_batch {
   // being joined back into the caller's stream.  `done_ev` marks the end of the run; the next ed_batch_run on this batch
   // waits for it (the buffers are reused), the accessors synchronise on it.  With two batches used alternately on ONE
   // stream, batch N's Viterbi tail and call table then run underneath batch N+1's emissions.
+  // Emission launch cut in two (single-group mode only): the first `split_frac` of the workgroups, an event, the rest.  The
+  // cohort pipeline (edcohort.inc) makes the NEXT slab's dispersion fit wait for that event, so that the fit is issued --
+  // in stream order, whatever the host's timing -- while this slab's emissions are under way.
+  double split_frac = 0.0;
+  hipEvent_t split_ev = nullptr;
+  bool split_recorded = false;          // the last run recorded split_ev
+  bool own_queues = false;              // streams of this batch are created with a (full) CU mask: a hardware queue each
   bool async_tail = false;
+  bool last_run_async = false;          // the last run left its tail on `fin` (done_ev marks its end)
   hipStream_t fin = nullptr;
   hipEvent_t done_ev = nullptr, fork_ev = nullptr;
   const int32_t* last_test = nullptr;   // inputs of the last ed_batch_run (for ed_batch_copy_call_info)
@@ -1595,10 +1606,13 @@ struct ed_batch {
   bool keep_loglik = true;   // fused mode only: also write the [E][3][S] likelihood matrix (the S4 `likelihood` slot)
   int fit_hist = 1;          // ed_batch_fit: 1 = iterate on count histograms (one pass over the counts), geometry picked from
                              // the data; 8 / 4 / 2 = that geometry (samples per workgroup of k_fit_hist); 0 = per cell
+  int fit_mode = 0;          // ed_batch_fit: 0 = maximum likelihood (Newton); 1 = aod::betabin's procedure (Nelder-Mead from the
+                             // glm start, optim()'s defaults) on the same histograms -- ed_batch_set_fit_mode
   bool timing = false;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_run_times = false, have_fit_time = false;
   double stage_total[5] = {0, 0, 0, 0, 0};   // sums of the stage times of all timed runs / fits since timing was enabled
+  float last_ms[5] = {0, 0, 0, 0, 0};        // stage times of the most recent folded run / fit (ed_batch_stage_ms)
   int64_t n_runs_timed = 0, n_fits_timed = 0;
 };
 
@@ -1671,6 +1685,16 @@ ED_EXPORT int ed_memcpy_d2h(void* dst, const void* src, size_t bytes)
 ED_EXPORT int ed_synchronize(void* stream)
 {
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return ED_OK;
+}
+
+// Device-to-host copy ordered on `st` and waited for there.  The accessors use this instead of hipMemcpy, which runs on the
+// legacy null stream and would wait for every blocking stream of the process -- and the streams of the cohort pipeline
+// (edcohort.inc) are blocking ones when they are created with a CU mask to get a hardware queue of their own.
+static int ed_d2h(void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return ED_OK;
 }
 
@@ -1919,6 +1943,26 @@ ED_EXPORT void ed_plan_destroy(ed_plan* p)
 
 ED_EXPORT int64_t ed_plan_n_exons(const ed_plan* p) { return p ? p->E : 0; }
 
+// A stream for the library's own use.  own_queue: created with a CU mask that names every CU -- the runtime gives such a
+// stream a hardware queue of its own instead of multiplexing it with others onto the GPU_MAX_HW_QUEUES shared ones, so which
+// of the pipeline's streams can run side by side no longer depends on how many streams the process created before (DESIGN.md
+// 4.10).  Such a stream is a blocking stream (it synchronises with the legacy null stream); the library itself never uses the
+// null stream on these paths.  Falls back to an ordinary non-blocking stream if the runtime refuses the mask.
+static hipError_t ed_stream_create(hipStream_t* st, bool own_queue, int device)
+{
+  if (own_queue) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
+      if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
+      if (hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();
+    }
+  }
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 // ---- batch ---------------------------------------------------------------------------------
 ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples)
 {
@@ -2042,7 +2086,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     b->jobs = jobs;
     const size_t n_groups = std::max<size_t>(b->group_off.size() - 1, 1);
     b->sides.resize(std::min<size_t>(n_groups, kSideStreams));
-    for (auto& sd : b->sides) HIP_TRY(hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
+    for (auto& sd : b->sides) HIP_TRY(ed_stream_create(&sd, false, plan->device));
     b->job_ev.resize(n_groups);
     for (auto& e : b->job_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     b->join_ev.resize(n_groups);
@@ -2078,22 +2122,25 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->join_ev) if (e) (void)hipEventDestroy(e);
   for (auto& sd : b->sides) if (sd) (void)hipStreamDestroy(sd);
   if (b->fin) (void)hipStreamDestroy(b->fin);
+  if (b->split_ev) (void)hipEventDestroy(b->split_ev);
   if (b->done_ev) (void)hipEventDestroy(b->done_ev);
   if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
   delete b;
 }
 
-// Add the stage times of the last timed run / fit to the running totals (called before their events are recorded
-// again, and by ed_batch_stage_ms_total).  The events belong to work issued earlier on this batch; with two batches
-// used alternately that work is a whole step old, so the synchronisation does not stall the pipeline.
-static int fold_stage_times(ed_batch* b)
+// Add the stage times of the last timed RUN to the running totals (called before its events are recorded again, and by
+// the readers).  The events belong to the previous run of this batch object; with batches used in rotation that work is a
+// whole step old, so the synchronisation does not stall the pipeline.  The fit's pair of events is folded separately --
+// before the NEXT fit records them again, or by a reader -- so that a run issued right after a fit on the same batch never
+// waits for that fit on the host.  last_ms keeps the most recent values for ed_batch_stage_ms.
+static int fold_run_times(ed_batch* b)
 {
   if (b->have_run_times) {
     HIP_TRY(hipEventSynchronize(b->ev[4]));
@@ -2101,15 +2148,21 @@ static int fold_stage_times(ed_batch* b)
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
       b->stage_total[i] += ms;
+      b->last_ms[i] = ms;
     }
     ++b->n_runs_timed;
     b->have_run_times = false;
   }
+  return ED_OK;
+}
+static int fold_fit_time(ed_batch* b)
+{
   if (b->have_fit_time) {
     HIP_TRY(hipEventSynchronize(b->ev[6]));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, b->ev[5], b->ev[6]));
     b->stage_total[4] += ms;
+    b->last_ms[4] = ms;
     ++b->n_fits_timed;
     b->have_fit_time = false;
   }
@@ -2122,6 +2175,7 @@ ED_EXPORT int ed_batch_enable_timing(ed_batch* b, int enable)
   b->timing = enable != 0;
   b->have_run_times = b->have_fit_time = false;
   for (double& t : b->stage_total) t = 0.0;
+  for (float& t : b->last_ms) t = 0.f;
   b->n_runs_timed = b->n_fits_timed = 0;
   return ED_OK;
 }
@@ -2143,7 +2197,7 @@ ED_EXPORT int ed_batch_set_async_tail(ed_batch* b, int on)
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   HIP_TRY(hipSetDevice(b->plan->device));
   if (on && !b->fin) {
-    HIP_TRY(hipStreamCreateWithFlags(&b->fin, hipStreamNonBlocking));
+    HIP_TRY(ed_stream_create(&b->fin, b->own_queues, b->plan->device));
     HIP_TRY(hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
   }
@@ -2154,7 +2208,7 @@ ED_EXPORT int ed_batch_set_async_tail(ed_batch* b, int on)
 ED_EXPORT int ed_batch_wait(ed_batch* b, void* stream_)
 {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
-  if (b->ran && b->async_tail && b->done_ev) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, b->done_ev, 0));
+  if (b->ran && b->last_run_async && b->done_ev) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, b->done_ev, 0));
   return ED_OK;
 }
 
@@ -2193,9 +2247,11 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   const int32_t C = p->C;
   const bool async = b->async_tail && !b->fused;
   hipStream_t tail = async ? b->fin : st;   // where the call table is built and the results become available
-  if (b->timing) { if (int rc = fold_stage_times(b)) return rc; }
-  if (async && b->ran) HIP_TRY(hipStreamWaitEvent(st, b->done_ev, 0));   // the previous run's tail still reads the buffers
+  if (b->timing) { if (int rc = fold_run_times(b)) return rc; }
+  // the previous run's asynchronous tail still reads the buffers -- whatever the mode of THIS run
+  if (b->ran && b->last_run_async && b->done_ev) HIP_TRY(hipStreamWaitEvent(st, b->done_ev, 0));
   b->stream = tail;
+  b->split_recorded = false;
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 16, st));
@@ -2253,9 +2309,22 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
                            b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr,
                            cold_flag);
-      if (nblk - head > 0)
-        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
-                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik,
+      // single-group mode with a split: [first part][split_ev][rest]; the cut is a multiple of 8 workgroups (XCD numbering)
+      int64_t cut = 0;
+      if (plain && b->group_off.size() == 2 && b->split_frac > 0.0 && b->split_frac < 1.0 && b->split_ev) {
+        cut = ((int64_t)((double)nblk * b->split_frac) / 8) * 8;
+        if (cut <= 0 || cut >= nblk) cut = 0;
+      }
+      if (cut > 0) {
+        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)cut), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
+                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr,
+                           cold_flag);
+        HIP_TRY(hipEventRecord(b->split_ev, st));
+        b->split_recorded = true;
+      }
+      if (nblk - head - cut > 0)
+        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head - cut)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
+                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head + cut, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik,
                            b->d_nerr, cold_flag);
       if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
         hipLaunchKernelGGL(k_emit_cold, dim3(512), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_seg, j0, j1, S, b->d_loglik,
@@ -2295,6 +2364,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   if (async) HIP_TRY(hipEventRecord(b->done_ev, tail));
   HIP_TRY(hipGetLastError());
   b->ran = true;
+  b->last_run_async = async;
   b->have_run_times = b->timing;
   return ED_OK;
 }
@@ -2445,7 +2515,7 @@ ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int3
     if (int rc = b->fitw->alloc(E, S)) return rc;
   }
   b->fit_stream = st;
-  if (b->timing) { if (int rc = fold_stage_times(b)) return rc; }
+  if (b->timing) { if (int rc = fold_fit_time(b)) return rc; }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
   const int64_t rows = (E - 1) / by + 1;
   if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist)) return rc;
@@ -2469,7 +2539,7 @@ ED_EXPORT int ed_batch_fit_n_unconverged(ed_batch* b, int64_t* n_unconverged, in
   HIP_TRY(hipSetDevice(b->plan->device));
   HIP_TRY(hipStreamSynchronize(b->fit_stream));
   std::vector<int> done((size_t)b->S);
-  HIP_TRY(hipMemcpy(done.data(), b->fitw->done, (size_t)b->S * 4, hipMemcpyDeviceToHost));
+  if (int rc = ed_d2h(done.data(), b->fitw->done, (size_t)b->S * 4, b->fit_stream)) return rc;
   int64_t n = 0;
   int32_t first = -1;
   for (int64_t s = 0; s < b->S; ++s)
@@ -2506,6 +2576,7 @@ ED_EXPORT int ed_batch_n_emit_launches(const ed_batch* b)
     const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
     n += (head > 0) + (nblk - head > 0);
   }
+  if (b->group_off.size() == 2 && b->split_frac > 0.0 && b->split_frac < 1.0 && b->split_ev) n += 1;
   return n;
 }
 
@@ -2535,7 +2606,7 @@ ED_EXPORT int ed_batch_n_calls(ed_batch* b, int64_t* n_calls)
 {
   if (int rc = batch_ready(b)) return rc;
   if (!n_calls) return ed_fail(ED_ERR_INVALID, "NULL output");
-  HIP_TRY(hipMemcpy(n_calls, b->d_total, 8, hipMemcpyDeviceToHost));
+  if (int rc = ed_d2h(n_calls, b->d_total, 8, b->stream)) return rc;
   if (*n_calls > b->calls_cap) {
     const ed_plan* p = b->plan;
     const int64_t cap = *n_calls + *n_calls / 8 + 1024;
@@ -2558,7 +2629,7 @@ ED_EXPORT int ed_batch_n_gsl_errors(ed_batch* b, int64_t* n_events)
   if (int rc = batch_ready(b)) return rc;
   if (!n_events) return ed_fail(ED_ERR_INVALID, "NULL output");
   unsigned long long v = 0;
-  HIP_TRY(hipMemcpy(&v, b->d_nerr, 8, hipMemcpyDeviceToHost));
+  if (int rc = ed_d2h(&v, b->d_nerr, 8, b->stream)) return rc;
   *n_events = (int64_t)v;
   return ED_OK;
 }
@@ -2570,7 +2641,7 @@ ED_EXPORT int ed_batch_copy_calls(ed_batch* b, ed_call* host_calls, int64_t cap)
   const int64_t k = std::min(n, cap);
   if (k > 0) {
     if (!host_calls) return ed_fail(ED_ERR_INVALID, "NULL output");
-    HIP_TRY(hipMemcpy(host_calls, b->d_calls, (size_t)k * sizeof(ed_call), hipMemcpyDeviceToHost));
+    if (int rc = ed_d2h(host_calls, b->d_calls, (size_t)k * sizeof(ed_call), b->stream)) return rc;
   }
   return ED_OK;
 }
@@ -2582,14 +2653,18 @@ ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int6
   const int64_t k = std::min(n, cap);
   if (k <= 0) return ED_OK;
   if (!host_info) return ed_fail(ED_ERR_INVALID, "NULL output");
-  DevBuf dinfo;
-  HIP_TRY(dinfo.alloc((size_t)k * sizeof(ed_call_info)));
+  if (k > b->info_cap) {
+    if (b->d_info) { HIP_TRY(hipFree(b->d_info)); b->d_info = nullptr; b->info_cap = 0; }
+    const int64_t cap = std::max<int64_t>(k + k / 4, 4096);
+    if (hipMalloc((void**)&b->d_info, (size_t)cap * sizeof(ed_call_info)) != hipSuccess)
+      return ed_fail(ED_ERR_NOMEM, "call decoration: cannot allocate %lld records", (long long)cap);
+    b->info_cap = cap;
+  }
   hipLaunchKernelGGL(k_call_info, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, b->stream, b->d_calls, k,
-                     (b->keep_loglik || !b->fused) ? b->d_loglik : (double*)nullptr, b->d_consts, b->last_test, b->last_ref, b->last_expected, b->S, dinfo.as<ed_call_info>(),
+                     (b->keep_loglik || !b->fused) ? b->d_loglik : (double*)nullptr, b->d_consts, b->last_test, b->last_ref, b->last_expected, b->S, b->d_info,
                      b->last_cov_X, b->last_cov_K, b->last_cov_beta);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  HIP_TRY(hipMemcpy(host_info, dinfo.p, (size_t)k * sizeof(ed_call_info), hipMemcpyDeviceToHost));
+  if (int rc = ed_d2h(host_info, b->d_info, (size_t)k * sizeof(ed_call_info), b->stream)) return rc;
   return ED_OK;
 }
 
@@ -2597,7 +2672,7 @@ ED_EXPORT int ed_batch_copy_path(ed_batch* b, uint8_t* host_path)
 {
   if (int rc = batch_ready(b)) return rc;
   if (!host_path) return ed_fail(ED_ERR_INVALID, "NULL output");
-  HIP_TRY(hipMemcpy(host_path, b->d_path, (size_t)b->plan->E * b->S, hipMemcpyDeviceToHost));
+  if (int rc = ed_d2h(host_path, b->d_path, (size_t)b->plan->E * b->S, b->stream)) return rc;
   return ED_OK;
 }
 
@@ -2607,7 +2682,7 @@ ED_EXPORT int ed_batch_copy_loglik(ed_batch* b, double* host_loglik)
   if (!host_loglik) return ed_fail(ED_ERR_INVALID, "NULL output");
   if ((b->fused && !b->keep_loglik) || !b->d_loglik)
     return ed_fail(ED_ERR_STATE, "the likelihood matrix is not kept (ed_batch_keep_loglik)");
-  HIP_TRY(hipMemcpy(host_loglik, b->d_loglik, (size_t)b->plan->E * 3 * b->S * 8, hipMemcpyDeviceToHost));
+  if (int rc = ed_d2h(host_loglik, b->d_loglik, (size_t)b->plan->E * 3 * b->S * 8, b->stream)) return rc;
   return ED_OK;
 }
 
@@ -2634,18 +2709,19 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));
   unsigned long long c[3] = {0, 0, 0};
-  HIP_TRY(hipMemcpy(c, dcnt.p, 24, hipMemcpyDeviceToHost));
+  if (int rc = ed_d2h(c, dcnt.p, 24, b->stream)) return rc;
   *n_mismatch = (int64_t)c[0];
   *n_compared = (int64_t)c[1];
   const int64_t k = std::min<int64_t>((int64_t)c[2], cap);
-  if (k > 0) HIP_TRY(hipMemcpy(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), hipMemcpyDeviceToHost));
+  if (k > 0) { if (int rc = ed_d2h(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), b->stream)) return rc; }
   return ED_OK;
 }
 
 ED_EXPORT int ed_batch_stage_ms_total(ed_batch* b, double ms_total[5], int64_t* n_runs, int64_t* n_fits)
 {
   if (!b || !ms_total) return ed_fail(ED_ERR_INVALID, "NULL argument");
-  if (int rc = fold_stage_times(b)) return rc;
+  if (int rc = fold_run_times(b)) return rc;
+  if (int rc = fold_fit_time(b)) return rc;
   for (int i = 0; i < 5; ++i) ms_total[i] = b->stage_total[i];
   if (n_runs) *n_runs = b->n_runs_timed;
   if (n_fits) *n_fits = b->n_fits_timed;
@@ -2655,18 +2731,13 @@ ED_EXPORT int ed_batch_stage_ms_total(ed_batch* b, double ms_total[5], int64_t* 
 ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
 {
   if (!b || !ms) return ed_fail(ED_ERR_INVALID, "NULL argument");
-  for (int i = 0; i < 5; ++i) ms[i] = 0.f;
-  if (b->have_run_times) {
-    HIP_TRY(hipEventSynchronize(b->ev[4]));
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
-  }
-  if (b->have_fit_time) {
-    HIP_TRY(hipEventSynchronize(b->ev[6]));
-    HIP_TRY(hipEventElapsedTime(&ms[4], b->ev[5], b->ev[6]));
-  }
+  if (int rc = fold_run_times(b)) return rc;     // (a pending pair of events becomes the "last" value)
+  if (int rc = fold_fit_time(b)) return rc;
+  for (int i = 0; i < 5; ++i) ms[i] = b->last_ms[i];
   return ED_OK;
 }
 
 #include "edrefset.inc"
 #include "edbins.inc"
 #include "edcov.inc"
+#include "edcohort.inc"

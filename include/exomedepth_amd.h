@@ -328,6 +328,77 @@ int ed_get_power_betabinom(int64_t n, const double* size, const double* phi, con
 int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi, const double* p, const double* alt_p,
                                 int theory, double* out);
 
+/* =====================================================================================
+ * 4. Cohort pipeline: slabs of a cohort through batch objects in rotation, on the library's own streams
+ * ===================================================================================== */
+
+/* The reference's user loops over the samples of a cohort (vignette/vignette.Rnw:390-431): per sample one
+ * new('ExomeDepth') -- aod::betabin (R/class_definition.R:118), then .Call get_loglike_matrix (:184-189) -- and one
+ * CallCNVs() -- one .Call C_hmm per chromosome (:354-374, R/tools.R:97).  A cohort object does that work for SLABS of
+ * samples: it owns its streams and `slabs_in_flight` batch objects used in rotation, and orders the stages of consecutive
+ * slabs with events so that the dispersion fit of slab t+1 and the Viterbi tail of slab t execute underneath the VALU-bound
+ * emissions of slabs t / t+1.  The schedule is built from stream order alone: it does not depend on the
+ * host's timing, on GPU_MAX_HW_QUEUES, or on the streams the process used before.  Results are those of ed_batch_fit +
+ * ed_batch_run on each slab, bit for bit.
+ *   slab_samples     samples per slab (the batch objects are sized for it; a last, smaller slab is accepted)
+ *   slabs_in_flight  1: every slab runs to completion before the next (no overlap); 2 (recommended) or more: pipelined.
+ * Options (ed_cohort_set_option, before the first submission unless noted):
+ *   "split"            fraction of a slab's emission launch after which the NEXT slab's fit is issued (default 0.30; 0 = at once)
+ *   "own_queues"       1 (default): every stream of the pipeline gets a hardware queue of its own; 0: ordinary streams
+ *   "fit_mode"         0 (default) maximum likelihood; 1 aod::betabin's Nelder-Mead procedure (ed_batch_set_fit_mode)
+ *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
+ *   "timing"           1: stage times are accumulated (ed_cohort_stage_ms_total); may be switched at any time (resets the sums) */
+typedef struct ed_cohort ed_cohort;
+int ed_cohort_create(ed_cohort** cohort, ed_plan* plan, int64_t slab_samples, int slabs_in_flight);
+void ed_cohort_destroy(ed_cohort* cohort);
+int ed_cohort_set_option(ed_cohort* cohort, const char* name, double value);
+
+/* Submit one slab whose counts are on the device: d_test / d_ref int32 [n_exons][n_samples] sample-minor, n_samples <=
+ * slab_samples.  d_phi / d_expected: DEVICE double[n_samples], or both NULL = fit them (ed_batch_fit).  ready_stream: a stream
+ * whose already enqueued work produces the counts (the pipeline waits for it on the device), NULL = they are complete.
+ * Asynchronous.  *ticket numbers the slabs from 0.  The results of a ticket stay available until `slabs_in_flight` further
+ * slabs have been submitted; its counts must stay valid until then too (the call decoration reads them). */
+int ed_cohort_submit(ed_cohort* cohort, const int32_t* d_test, const int32_t* d_ref, int64_t n_samples, const double* d_phi,
+                     const double* d_expected, double mixture, void* ready_stream, int64_t* ticket);
+/* The batch object holding a ticket's results -- read them with the ed_batch_* accessors (ed_batch_n_calls, ed_batch_copy_*,
+ * ed_batch_path, ...), which wait for that slab only -- and the DEVICE arrays of its (phi, expected).  ED_ERR_STATE once the
+ * ticket's slot has been reused. */
+int ed_cohort_batch(ed_cohort* cohort, int64_t ticket, ed_batch** batch, const double** d_phi, const double** d_expected);
+int ed_cohort_wait(ed_cohort* cohort, int64_t ticket);   /* host waits for that slab's call table */
+int ed_cohort_drain(ed_cohort* cohort);                  /* ... for everything submitted so far */
+void* ed_cohort_stream(ed_cohort* cohort);               /* the pipeline's main stream (a hipStream_t) */
+/* ed_batch_stage_ms_total summed over the cohort's batch objects; launches of the emission kernel per slab */
+int ed_cohort_stage_ms_total(ed_cohort* cohort, double ms_total[5], int64_t* n_runs, int64_t* n_fits);
+int ed_cohort_n_emit_launches(ed_cohort* cohort);
+
+/* ---- slabs from host memory (ingest) ----
+ * layout 0: the host matrix is [n_exons][row_stride] sample-minor (the EDCOUNT1 container of exomedepth_amd/io.py); the slab
+ *           is its first n_samples columns from the given pointer (row_stride = the cohort's width for a window of columns)
+ * layout 1: the host matrix is R's n_exons x n_samples integer matrix, column-major (row_stride ignored); transposed on the
+ *           device to the pipeline's sample-minor layout
+ * wire 4: int32 elements; wire 2: uint16 elements, widened on the device (counts below 65536: half the PCIe bytes)
+ * Pinned host memory (ed_host_alloc) is read by the DMA engine in place; pageable memory goes through the cohort's pinned
+ * double buffer (a few host threads copy chunk k+1 while chunk k is on the link).  Uploads run on a copy stream of the
+ * cohort and overlap the compute of earlier slabs.  phi / expected: DEVICE arrays or NULL (fit), as ed_cohort_submit.
+ * The slot's device buffers are reused: collect the results of ticket - slabs_in_flight first. */
+int ed_cohort_submit_host(ed_cohort* cohort, const void* test, const void* ref, int64_t n_samples, int layout, int wire,
+                          int64_t row_stride, const double* d_phi, const double* d_expected, double mixture, int64_t* ticket);
+int ed_cohort_ingest_stats(ed_cohort* cohort, double* bytes, double* host_seconds);
+int ed_host_alloc(void** hptr, size_t bytes);   /* pinned host memory */
+int ed_host_free(void* hptr);
+
+/* CallCNVs for a whole cohort held in host memory -- what the R-level wrapper ed_call_cnvs_batch (shim/edcore_shim.c) calls:
+ * n_total samples cut into slabs, uploaded, fitted (phi == NULL) or given (HOST phi[n_total], expected[n_total]), run, and
+ * collected while later slabs compute.  Host outputs (each may be NULL): phi_out / expected_out [n_total]; path_out uint8 in
+ * the layout of the input (layout 1: [n_total][n_exons], R's n_exons x n_total matrix; layout 0: [n_exons][n_total]).
+ * The call table (sample = column of the cohort) and its decoration are kept by the cohort: *n_calls rows, copied out with
+ * ed_cohort_copy_calls; ed_cohort_run_status gives the number of samples whose fit did not converge and of GSL error events. */
+int ed_cohort_run_host(ed_cohort* cohort, const void* test, const void* ref, int64_t n_total, int layout, int wire,
+                       const double* phi, const double* expected, double mixture, double* phi_out, double* expected_out,
+                       uint8_t* path_out, int64_t* n_calls);
+int ed_cohort_copy_calls(ed_cohort* cohort, ed_call* calls, ed_call_info* info, int64_t cap);
+int ed_cohort_run_status(ed_cohort* cohort, int64_t* n_unconverged, int64_t* n_gsl_errors);
+
 /* ---- utilities ---- */
 /* device memory through the library, for callers without a HIP binding (tests, R shim) */
 int ed_malloc(void** dptr, size_t bytes);

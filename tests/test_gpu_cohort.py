@@ -1,0 +1,151 @@
+"""The cohort pipeline of the library (ed_cohort_*: own streams, batch rotation, event-ordered stages, ingest from host
+memory): the same bits as ed_batch_fit + ed_batch_run slab by slab, whatever the options, layouts and wire formats.
+Counterpart in the reference: the user's loop over samples, vignette/vignette.Rnw:390-431."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_results(edlib, plan, slabs):
+    """slab by slab, synchronously, through the batch interface"""
+    out = []
+    for test, ref in slabs:
+        n = test.shape[1]
+        b = edlib.Batch(plan, n)
+        dphi = edlib.DeviceArray(np.zeros(n)); dexp = edlib.DeviceArray(np.zeros(n))
+        b.fit(test, ref, dphi, dexp)
+        b.run(test, ref, dphi, dexp)
+        out.append({"calls": b.calls().copy(), "info": b.call_info().copy(), "path": b.path().copy(), "loglik": b.loglik().copy(),
+                    "phi": dphi.to_host(), "expected": dexp.to_host()})
+        b.close()
+    return out
+
+
+def _same(got, want, keys):
+    for k in keys:
+        assert got[k].tobytes() == want[k].tobytes(), k
+
+
+@pytest.fixture(scope="module")
+def cohort_data(edlib):
+    from exomedepth_amd import synth
+    E, C, S = 12000, 5, 160
+    chrom_off, start, end = synth.exon_design(E, C, seed=11)
+    slabs = []
+    for k, n in enumerate((S, S, S, S, 70)):                       # the last slab is ragged
+        test, ref, _, _, _ = synth.counts_numpy(chrom_off, n, seed=300 + k, n_segments=4, mean_depth=80.0)
+        slabs.append((test, ref))
+    plan = edlib.Plan(chrom_off, start, end)
+    want = _reference_results(edlib, plan, slabs)
+    yield edlib, plan, slabs, want, S
+    plan.close()
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(own_queues=0), dict(split=0.0), dict(split=0.6, viterbi_overlap=1), dict(own_queues=0, split=0.5)])
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_device_slabs_through_the_cohort_equal_the_batch_interface(cohort_data, opts, in_flight):
+    edlib, plan, slabs, want, S = cohort_data
+    co = edlib.Cohort(plan, S, in_flight, timing=1, **opts)
+    dev = [(edlib.DeviceArray(t), edlib.DeviceArray(r)) for t, r in slabs]
+    tickets = []
+    for rounds in range(2):                                        # every slot is reused while its predecessor is in flight
+        for i, (dt, dr) in enumerate(dev):
+            n = slabs[i][0].shape[1]
+            if len(tickets) >= in_flight:                          # results of the ticket whose slot is about to be reused
+                j = len(tickets) - in_flight
+                got = co.results(tickets[j], slabs[j % len(slabs)][0].shape[1], path=True, loglik=True)
+                _same(got, want[j % len(slabs)], ("calls", "info", "path", "loglik", "phi", "expected"))
+            tickets.append(co.submit(dt, dr, n_samples=n))
+    for j in range(len(tickets) - in_flight, len(tickets)):
+        got = co.results(tickets[j], slabs[j % len(slabs)][0].shape[1], path=True, loglik=True)
+        _same(got, want[j % len(slabs)], ("calls", "info", "path", "loglik", "phi", "expected"))
+    with pytest.raises(edlib.EdError):                             # overwritten long ago
+        co.batch(tickets[0])
+    tot, nr, nf = co.stage_ms_total()
+    assert nr == len(tickets) and nf == len(tickets) and tot["emissions"] > 0
+    co.close()
+
+
+def test_given_parameters_and_mixture(cohort_data, oracle):
+    edlib, plan, slabs, want, S = cohort_data
+    test, ref = slabs[1]
+    rng = np.random.default_rng(3)
+    phi = rng.uniform(0.002, 0.02, S); p = rng.uniform(0.08, 0.2, S)
+    b = edlib.Batch(plan, S)
+    b.run(test, ref, phi, p, mixture=0.6)
+    ref_calls, ref_path = b.calls().copy(), b.path().copy()
+    b.close()
+    co = edlib.Cohort(plan, S, 2)
+    t0 = co.submit(edlib.DeviceArray(test), edlib.DeviceArray(ref), phi=edlib.DeviceArray(phi), expected=edlib.DeviceArray(p), mixture=0.6)
+    got = co.results(t0, S, path=True)
+    assert got["calls"].tobytes() == ref_calls.tobytes() and got["path"].tobytes() == ref_path.tobytes()
+    assert got["phi"].tobytes() == phi.tobytes() and got["expected"].tobytes() == p.tobytes()
+    co.close()
+
+
+@pytest.mark.parametrize("layout,wire,pinned", [(0, 4, False), (0, 2, False), (1, 4, False), (1, 2, False), (0, 4, True), (1, 2, True), (0, 2, True)])
+def test_whole_cohort_from_host_memory(cohort_data, layout, wire, pinned):
+    """ed_cohort_run_host: the cohort's matrix in host memory -- sample-minor or R's column-major, int32 or the 16-bit wire
+    format, pageable (staged through the pinned double buffer) or pinned (read in place) -- cut into slabs of 160 + 160 + ... + 70."""
+    edlib, plan, slabs, want, S = cohort_data
+    E = plan.n_exons
+    test = np.concatenate([t for t, _ in slabs], axis=1)           # (E, 710)
+    ref = np.concatenate([r for _, r in slabs], axis=1)
+    St = test.shape[1]
+    dt = np.int32 if wire == 4 else np.uint16
+    assert test.max() < 65536 and ref.max() < 65536
+    th = test.astype(dt) if layout == 0 else np.ascontiguousarray(test.T.astype(dt))
+    rh = ref.astype(dt) if layout == 0 else np.ascontiguousarray(ref.T.astype(dt))
+    keep = []
+    if pinned:
+        pt, pr = edlib.PinnedArray(th.shape, dt), edlib.PinnedArray(rh.shape, dt)
+        pt.array[...] = th; pr.array[...] = rh
+        th, rh = pt.array, pr.array
+        keep = [pt, pr]
+    co = edlib.Cohort(plan, S, 2)
+    for rep in range(2):                                           # the second pass reuses every buffer of the first
+        out = co.run_host(th, rh, layout, want_path=True)
+        calls = np.concatenate([w["calls"] for w in want])
+        shift = np.concatenate([np.full(len(w["calls"]), k * S, dtype=np.int32) for k, w in enumerate(want)])
+        calls["sample"] += shift
+        assert out["calls"].tobytes() == calls.tobytes()
+        assert out["info"].tobytes() == np.concatenate([w["info"] for w in want]).tobytes()
+        assert out["phi"].tobytes() == np.concatenate([w["phi"] for w in want]).tobytes()
+        assert out["expected"].tobytes() == np.concatenate([w["expected"] for w in want]).tobytes()
+        path = np.concatenate([w["path"] for w in want], axis=1)
+        assert np.array_equal(out["path"] if layout == 0 else out["path"].T, path)
+        assert out["n_unconverged"] == 0 and out["n_gsl_errors"] == 0
+    nbytes, host_s = co.ingest_stats()
+    assert nbytes == 2 * 2 * E * St * wire
+    # given parameters from host vectors
+    rng = np.random.default_rng(8)
+    phi = rng.uniform(0.002, 0.02, St); p = rng.uniform(0.08, 0.2, St)
+    out = co.run_host(th, rh, layout, phi=phi, expected=p, want_path=True)
+    b = edlib.Batch(plan, St)
+    b.run(test, ref, phi, p)
+    assert out["calls"].tobytes() == b.calls().tobytes()
+    assert np.array_equal(out["path"] if layout == 0 else out["path"].T, b.path())
+    b.close()
+    co.close()
+    del keep
+
+
+def test_stage_ms_reports_the_last_fit_and_run_after_folding(cohort_data):
+    """after the canonical fit -> run sequence ed_batch_stage_ms must report both, also after ed_batch_stage_ms_total"""
+    edlib, plan, slabs, want, S = cohort_data
+    test, ref = slabs[0]
+    b = edlib.Batch(plan, S)
+    b.enable_timing(True)
+    dphi = edlib.DeviceArray(np.zeros(S)); dexp = edlib.DeviceArray(np.zeros(S))
+    dt, dr = edlib.DeviceArray(test), edlib.DeviceArray(ref)
+    for _ in range(2):
+        b.fit(dt, dr, dphi, dexp)
+        b.run(dt, dr, dphi, dexp)
+    ms = b.stage_ms()
+    assert ms["fit"] > 0 and ms["emissions"] > 0
+    tot, nr, nf = b.stage_ms_total()
+    assert nr == 2 and nf == 2
+    ms2 = b.stage_ms()
+    assert ms2["fit"] == ms["fit"] and ms2["emissions"] == ms["emissions"]
+    b.close()
