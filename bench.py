@@ -151,6 +151,121 @@ def cpu_baseline(test_h, ref_h, p, phi, chrom_off, start, end, fit, allcores=0):
             "emissions_s": t_emit, "viterbi_s": t_vit, "fit_s": t_fit}
 
 
+def _device_view(torch, eddist, ptr, shape, typestr, dev):
+    return torch.as_tensor(eddist._DevicePointer(ptr, shape, typestr), device=dev)
+
+
+def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_batches, test, ref, phi, p, phi_fit, p_fit, fitted,
+                          chrom_off, start, end, k):
+    """k columns of each of the last slabs in flight against the CPU checker (oracle/, the checker -- never the thing timed):
+    the bits of the likelihood matrix vs its portable flavour, Viterbi states and call rows vs its Viterbi run on its own matrix,
+    given the (phi, expected) the device used for that slab."""
+    from oracle import edoracle as eo
+    eo.build()
+    E, S = test.shape
+    cols = sorted(set(int(c) for c in np.linspace(0, S - 1, k).round()))
+    out = {"columns": 0, "loglik_values": 0, "loglik_bit_mismatches": 0, "discordant_states": 0, "discordant_calls": 0, "slabs": 0}
+    slabs = []
+    if co is not None:
+        for t in range(max(0, last_ticket - n_batches + 1), last_ticket + 1):
+            b, pp, pe = co.batch(t)
+            b.n_samples = S
+            slabs.append((b, _device_view(torch, eddist, pp, (S,), "<f8", dev).cpu().numpy(), _device_view(torch, eddist, pe, (S,), "<f8", dev).cpu().numpy()))
+    else:
+        for j, b in enumerate(batches):
+            ph = phi_fit[j].cpu().numpy() if fitted else phi.cpu().numpy()
+            pe = p_fit[j].cpu().numpy() if fitted else p.cpu().numpy()
+            slabs.append((b, ph, pe))
+    th = test[:, cols].cpu().numpy()
+    rh = ref[:, cols].cpu().numpy()
+    for b, ph, pe in slabs:
+        calls = b.calls()
+        ptr = b.device_pointers()
+        ll = _device_view(torch, eddist, ptr["loglik"], (E, 3, S), "<f8", dev)[:, :, cols].cpu().numpy()
+        path = _device_view(torch, eddist, ptr["path"], (E, S), "|u1", dev)[:, cols].cpu().numpy()
+        out["slabs"] += 1
+        for i, c in enumerate(cols):
+            ell, _ = eo.get_loglike_matrix(ph[c], pe[c], th[:, i] + rh[:, i], th[:, i], 1.0, eo.PORTABLE)
+            got = np.ascontiguousarray(ll[:, :, i])
+            out["loglik_values"] += int(got.size)
+            out["loglik_bit_mismatches"] += int(np.sum(got.view(np.int64) != np.ascontiguousarray(ell).view(np.int64)))
+            epath, ecalls = eo.callcnvs(ell, chrom_off, start, end)
+            out["discordant_states"] += int(np.sum(path[:, i].astype(np.int8) != epath))
+            mine = calls[calls["sample"] == c]
+            want = {(int(r[0]) - 1, int(r[1]) - 1, int(r[2]), int(r[3])) for r in ecalls}
+            have = {(int(r["start_exon"]), int(r["end_exon"]), int(r["type"]), int(r["nexons"])) for r in mine}
+            out["discordant_calls"] += len(want ^ have)
+            out["columns"] += 1
+    out["what"] = ("%d columns x %d slab(s) in flight after the timed region: likelihood bits vs the checker's portable flavour, Viterbi "
+                   "states and call rows vs the checker's Viterbi, given the (phi, expected) the device used" % (len(cols), len(slabs)))
+    return out
+
+
+def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
+    """The same steps with the counts coming from HOST memory for every slab (ed_cohort_submit_host: copy stream, device slabs
+    double-buffered by the slots, the 16-bit wire format widened on the device): the PCIe-inclusive rate.  Reported beside `value`,
+    never instead of it.  Pinned host memory is read by the DMA engine in place; pageable memory goes through the library's pinned
+    double buffer (host threads copy chunk k+1 while chunk k is on the link)."""
+    dt = np.uint16 if args.wire == 2 else np.int32
+    th, rh = test.cpu().numpy(), ref.cpu().numpy()
+    if args.wire == 2 and (th.max() >= 65536 or rh.max() >= 65536):
+        return {"value_with_h2d": None, "note": "counts beyond 65535: the 16-bit wire format does not apply"}
+    out = {}
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            pt, pr = ed.PinnedArray((E, S), dt), ed.PinnedArray((E, S), dt)
+            pt.array[...] = th; pr.array[...] = rh
+            ht, hr = pt.array, pr.array
+        else:
+            ht, hr = th.astype(dt), rh.astype(dt)
+        co = ed.Cohort(plan, S, max(2, n_batches))
+        sub = (lambda: co.submit_host(ht, hr, 0)) if args.fit else (lambda: co.submit_host(ht, hr, 0, phi=phi, expected=p))
+        for _ in range(max(2, n_batches) + 1):
+            sub()
+        co.drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tk = sub()
+        co.drain()
+        el = time.perf_counter() - t0
+        nbytes = 2.0 * E * S * args.wire
+        out[kind] = {"ms_per_step": el / args.steps * 1e3, "value": E * S * args.steps / el, "link_GBps": nbytes * args.steps / el / 1e9}
+        co.close()
+        if kind == "pinned":
+            pt.free(); pr.free()
+    return {"value_with_h2d": out["pinned"]["value"], "unit": "exons*samples/s", "wire_bytes_per_count": args.wire,
+            "bytes_per_step": 2.0 * E * S * args.wire, "pinned": out["pinned"], "pageable": out["pageable"],
+            "pcie_peak_GBps": 63.0,
+            "note": "every step uploads both count matrices of its slab from host memory (PCIe Gen5 x16: 63 GB/s peak) on the cohort's copy "
+                    "stream while earlier slabs compute; link_GBps = bytes on the link / wall time of the steps"}
+
+
+def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps):
+    """BASELINE configs[1]: 200 000 exons x 64 samples, phi given (no fit) -- the first 64 columns of the batch through the cohort
+    pipeline (two slabs in flight), and one slab at a time (the latency of a lone slab: bound by the longest chromosome's chain)."""
+    n = 64
+    t64, r64 = test[:, :n].contiguous(), ref[:, :n].contiguous()
+    ph, pe = phi[:n].contiguous(), p[:n].contiguous()
+    res = {}
+    for name, in_flight in (("pipelined", 2), ("one_at_a_time", 1)):
+        co = ed.Cohort(plan, n, in_flight)
+        for _ in range(3):
+            co.submit(t64, r64, phi=ph, expected=pe, n_samples=n)
+        co.drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tk = co.submit(t64, r64, phi=ph, expected=pe, n_samples=n)
+        co.drain()
+        el = time.perf_counter() - t0
+        b, _, _ = co.batch(tk)
+        res[name] = {"ms_per_step": el / steps * 1e3, "value": E * n * steps / el, "n_calls": b.n_calls()}
+        co.close()
+    return {"workload": "BASELINE.json configs[1]: %d exons x 64 samples, phi given per sample (no fit), 1 GPU" % E, "steps": steps,
+            "unit": "exons*samples/s", **res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +304,10 @@ def main():
     ap.add_argument("--stage-inputs", type=int, default=0, help="1: additionally time the same steps with the counts uploaded from pinned host "
                     "memory for every slab (copy stream, double-buffered device slabs): reported as value_with_h2d, never as value")
     ap.add_argument("--wire", type=int, default=2, help="--stage-inputs: bytes per count on the link (2 = uint16 widened on the device, 4 = int32)")
+    ap.add_argument("--fit-concordance", type=int, default=64, help="columns of the batch on which the whole path is run twice after the timed "
+                    "region -- maximum-likelihood fit vs aod::betabin's Nelder-Mead procedure -- and the differences counted (0 = skip)")
+    ap.add_argument("--config1-steps", type=int, default=20, help="timed steps of the BASELINE configs[1] leg (200 000 x 64, phi given) run after "
+                    "the headline and reported under extra.config1 (0 = skip)")
     ap.add_argument("--verify-columns", type=int, default=4, help="columns of the last slabs checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
@@ -436,7 +555,7 @@ def main():
             par = (ed.api._RawDevice(pp), ed.api._RawDevice(pe)) if args.fit else (phi, p)
             reset_timing()
             for _ in range(3):
-                co.submit(test, ref, phi=par[0], expected=par[1], n_samples=S)
+                last_ticket[0] = co.submit(test, ref, phi=par[0], expected=par[1], n_samples=S)
                 co.drain()
             alone_ms = co.stage_ms_total()[0]["emissions"] / 3.0
         else:
@@ -447,6 +566,24 @@ def main():
                 torch.cuda.synchronize()
                 bb.wait()
             alone_ms = bb.stage_ms()["emissions"]
+
+    # ---- after the timed region: the bench checks what it timed, and carries the legs the headline does not -----------------
+    verify = None
+    if rank == 0 and args.verify_columns > 0 and plain and not args.fused:
+        verify = verify_against_oracle(ed, eddist, torch, dev, co if use_cohort else None, batches, last_ticket[0] if use_cohort else None,
+                                       n_batches, test, ref, phi, p, phi_fit if not use_cohort else None, p_fit if not use_cohort else None,
+                                       bool(args.fit), chrom_off, start, end, args.verify_columns)
+    fit_conc = None
+    if rank == 0 and args.fit and plain and not args.fused and args.fit_concordance > 0:
+        from exomedepth_amd import concordance
+        k = min(args.fit_concordance, S)
+        fit_conc = concordance.fit_mode_concordance(plan, test[:, :k].contiguous(), ref[:, :k].contiguous())
+    config1 = None
+    if rank == 0 and args.config1_steps > 0 and plain and not args.fused and S >= 64:
+        config1 = config1_leg(ed, torch, plan, test, ref, phi, p, E, args.config1_steps)
+    staged = None
+    if rank == 0 and args.stage_inputs and use_cohort:
+        staged = staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
 
     if rank == 0:
         kernel = "k_emit_viterbi" if args.fused else ("k_emit_batch" if plain else "k_emit_bins")
@@ -496,7 +633,13 @@ def main():
                              "`call_table` are latencies of the batch's tail on its own streams and `fit` runs on a second stream: "
                              "they overlap the emissions of the neighbouring batch and do not add up to ms_per_step",
             "n_calls": n_calls,
+            "verify": verify,
+            "fit_concordance": fit_conc,
+            "extra": {"config1": config1},
         }
+        if staged:
+            out["value_with_h2d"] = staged.pop("value_with_h2d")
+            out["h2d"] = staged
         if world == 1 and args.cpu_samples > 0:
             k = min(args.cpu_samples, S)
             ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

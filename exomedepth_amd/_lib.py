@@ -107,6 +107,9 @@ SYMBOLS = [
     ("ed_cohort_run_host", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, C.POINTER(_i64)]),
     ("ed_cohort_copy_calls", C.c_int, [_vp, _vp, _vp, _i64]),
     ("ed_cohort_run_status", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("ed_fit_betabin_host", C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    ("ed_select_reference_set_host", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64)]),
+    ("ed_batch_set_fit_mode", C.c_int, [_vp, C.c_int]),
     ("ed_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
     ("ed_free", C.c_int, [_vp]),
     ("ed_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t]),

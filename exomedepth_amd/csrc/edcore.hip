@@ -2381,6 +2381,7 @@ struct FitWork {
   double* eta = nullptr;
   double* lam = nullptr;
   int* done = nullptr;
+  int* fevals = nullptr;       // fit mode 1: objective evaluations of each sample's Nelder-Mead search
   uint32_t* hist = nullptr;    // count histograms (k_fit_hist; layout and size depend on the geometry, sized for the largest)
   int32_t* ov_y = nullptr;     // [lists][cap][S] cells beyond the histogram range, per row group of k_fit_hist
   int32_t* ov_r = nullptr;
@@ -2422,6 +2423,8 @@ struct FitWork {
     HIP_TRY(hipMalloc((void**)&eta, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&lam, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&done, (size_t)S * 4));
+    HIP_TRY(hipMalloc((void**)&fevals, (size_t)S * 4));
+    HIP_TRY(hipMemset(fevals, 0, (size_t)S * 4));
     HIP_TRY(hipMalloc((void**)&depth, 4));
     HIP_TRY(hipHostMalloc((void**)&h_depth, 4, hipHostMallocDefault));
     *h_depth = -1;
@@ -2429,11 +2432,11 @@ struct FitWork {
   }
   void release()
   {
-    void* ptrs[] = {partial, eta, lam, done, hist, ov_y, ov_r, ovn, depth};
+    void* ptrs[] = {partial, eta, lam, done, fevals, hist, ov_y, ov_r, ovn, depth};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h_depth) (void)hipHostFree(h_depth);
     h_depth = nullptr;
-    partial = eta = lam = nullptr; done = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr; depth = nullptr;
+    partial = eta = lam = nullptr; done = nullptr; fevals = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr; depth = nullptr;
   }
 };
 
@@ -2446,7 +2449,7 @@ static void fitwork_free(FitWork* w)
 // use_hist: build count histograms once and iterate on them in one launch (needs one test column per sample laid
 // out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
-                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0)
+                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0, int fit_mode = 0)
 {
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
   const int64_t nch = nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
@@ -2454,9 +2457,11 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
-  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, E >= 65536 ? 16 : 4, w.partial);
+  // (fit mode 1 starts from aod's glm-binomial intercept logit(sum y / sum n) over ALL exons; the Newton fit only needs a rough start)
+  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial);
   HIP_TRY(hipMemsetAsync(w.depth, 0, 4, st));
   hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
+  if (fit_mode == 1 && !use_hist) return ed_fail(ED_ERR_STATE, "fit mode 1 (aod-nm) works on the count histograms: ed_batch_set_fit_histograms(batch, 0) excludes it");
   if (use_hist) {
     if (tcs != 1 || trs != rrs) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
     if (int rc = w.alloc_hist()) return rc;
@@ -2472,6 +2477,18 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
                          dim3(NS::kHistBlock), 0, st, d_test, d_ref, rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, CAP, w.depth, launched);
     ED_FIT_HIST(hg8, w.cap8) ED_FIT_HIST(hg4, w.cap4) ED_FIT_HIST(hg2, w.cap2)
 #undef ED_FIT_HIST
+#define ED_FIT_NM(NS, CAP)                                                                                                         \
+    if (launched & fit_hist_bit(NS::kHistSamples))                                                                                 \
+      hipLaunchKernelGGL(NS::k_fit_hnm, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y,     \
+                         w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 2000 /* optim(control = list(maxit = 2000)) */, d_test, d_ref, rrs,  \
+                         E, w.depth, launched, w.fevals);
+    if (fit_mode == 1) {
+      ED_FIT_NM(hg8, w.cap8) ED_FIT_NM(hg4, w.cap4) ED_FIT_NM(hg2, w.cap2)
+      hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
+      HIP_TRY(hipGetLastError());
+      return ED_OK;
+    }
+#undef ED_FIT_NM
 #define ED_FIT_NEWTON(NS, CAP)                                                                                                     \
     if (launched & fit_hist_bit(NS::kHistSamples))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
@@ -2518,7 +2535,7 @@ ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int3
   if (b->timing) { if (int rc = fold_fit_time(b)) return rc; }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
   const int64_t rows = (E - 1) / by + 1;
-  if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist)) return rc;
+  if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist, b->fit_mode)) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[6], st));
   b->have_fit_time = b->timing;
   return ED_OK;
@@ -2563,6 +2580,14 @@ ED_EXPORT int ed_batch_set_fit_histograms(ed_batch* b, int on)
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (on != 0 && on != 1 && on != 2 && on != 4 && on != 8) return ed_fail(ED_ERR_INVALID, "ed_batch_set_fit_histograms: 0, 1 (automatic), or a geometry 8 / 4 / 2");
   b->fit_hist = on;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_set_fit_mode(ed_batch* b, int mode)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  if (mode != 0 && mode != 1) return ed_fail(ED_ERR_INVALID, "ed_batch_set_fit_mode: 0 (maximum likelihood) or 1 (aod-nm)");
+  b->fit_mode = mode;
   return ED_OK;
 }
 

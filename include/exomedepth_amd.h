@@ -145,6 +145,14 @@ int ed_batch_fit_n_unconverged(ed_batch* batch, int64_t* n_unconverged, int32_t*
  * bins up to 4096 / 8192 / 16384 for the reference and total counts), picked on the device from the batch's depth;
  * on = 8, 4 or 2 asks for one of them (what the tests do), 1 leaves the choice to the data. */
 int ed_batch_set_fit_histograms(ed_batch* batch, int on);
+/* Which estimate ed_batch_fit returns.
+ *   0 (default)  the maximum-likelihood estimate, by Newton's method on the count histograms (converged to 1e-9);
+ *   1 "aod-nm"   the procedure the reference runs: aod::betabin's objective (binomial coefficients included) minimised by
+ *                optim()'s Nelder-Mead (R's nmmin: alpha 1, beta 0.5, gamma 2, reltol sqrt(eps) on the objective, maxit 2000)
+ *                from aod's start (glm-binomial intercept logit(sum y / sum n), phi = 0.1), evaluated on the same histograms.
+ *                It stops where Nelder-Mead stops -- within ~1e-3 of the maximum in phi -- so its (phi, expected) are
+ *                reference-LIKE parameters; aod is not in the reference tree, so neither mode is pinned against it. */
+int ed_batch_set_fit_mode(ed_batch* batch, int mode);
 /* The same fit on every `by`-th exon only (exons 0, by, 2*by, ...): the scalar form of subset.for.speed,
  * reference R/class_definition.R:107-113, where by = floor(n_exons / subset.for.speed).  by = 1 is ed_batch_fit. */
 int ed_batch_fit_subset(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, int64_t by, double* d_phi,
@@ -398,6 +406,18 @@ int ed_cohort_run_host(ed_cohort* cohort, const void* test, const void* ref, int
                        uint8_t* path_out, int64_t* n_calls);
 int ed_cohort_copy_calls(ed_cohort* cohort, ed_call* calls, ed_call_info* info, int64_t cap);
 int ed_cohort_run_status(ed_cohort* cohort, int64_t* n_unconverged, int64_t* n_gsl_errors);
+
+/* The model fit of new('ExomeDepth') alone, for every column of a host-resident cohort: what stands where the reference calls
+ * aod::betabin(cbind(test, reference) ~ 1, random = ~ 1) and fitted(mod) (R/class_definition.R:118-119, :168).  layout / wire as
+ * ed_cohort_submit_host (a dense matrix: layout 0 [n_exons][n_samples], layout 1 R's column-major n_exons x n_samples).
+ * fit_mode as ed_batch_set_fit_mode.  converged_out (optional) int32[n_samples]: 1 = converged. */
+int ed_fit_betabin_host(const void* test, const void* ref, int64_t n_exons, int64_t n_samples, int layout, int wire, int fit_mode,
+                        double* phi_out, double* expected_out, int32_t* converged_out);
+/* ed_select_reference_set on host data in R's layout: test.counts integer[n_bins], reference.counts the n_bins x n_refs integer
+ * matrix column-major (uploaded and transposed on the device). */
+int ed_select_reference_set_host(const int32_t* test, const int32_t* refs_colmajor, int64_t n_bins, int64_t n_refs,
+                                 const double* bin_length, int64_t n_bins_reduced, ed_refset_row* rows, int32_t* n_chosen,
+                                 int64_t* n_selected_bins);
 
 /* ---- utilities ---- */
 /* device memory through the library, for callers without a HIP binding (tests, R shim) */

@@ -234,12 +234,13 @@ def fit_mle_cov(test, ref, X):
     return beta, phi.value, ll.value, it
 
 
-def fit_nm(test, ref):
-    """Nelder-Mead stand-in for aod::betabin (timing baseline only)."""
+def fit_nm(test, ref, with_status=False):
+    """aod::betabin's documented procedure (its objective, R's nmmin from the glm start, optim()'s defaults): (phi, p, function
+    evaluations[, nmmin's fail code]).  A stand-in -- aod is not in the reference tree."""
     test = _i32(test); ref = _i32(ref)
     phi, p, ne = C.c_double(), C.c_double(), C.c_int()
-    lib().edo_fit_nm(test, ref, test.size, C.byref(phi), C.byref(p), C.byref(ne))
-    return phi.value, p.value, ne.value
+    fail = lib().edo_fit_nm(test, ref, test.size, C.byref(phi), C.byref(p), C.byref(ne))
+    return (phi.value, p.value, ne.value, fail) if with_status else (phi.value, p.value, ne.value)
 
 
 # ---- the reference's own special functions, compiled as they lie (container only) ----

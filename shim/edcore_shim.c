@@ -5,7 +5,8 @@
  *     .Call("get_loglike_matrix", phi, expected, total, observed, mixture)        reference src/CNV_estimate.cpp:16, :52-85
  *     .Call("C_hmm", nstates, nobs, transitions, probabilities, positions, L)     reference src/hmm.cpp:13, :18-167
  * registered exactly as reference src/ExomeDepth_init.c:14-24 registers them ({"C_hmm", 6}, {"get_loglike_matrix", 5},
- * dynamic symbols off).  Inputs stay R-owned and read-only; outputs are R allocations; the library copies in, launches,
+ * dynamic symbols off) -- plus, next to them, the three cohort-level entries at the end of this file (ed_call_cnvs_batch,
+ * ed_fit_betabin_batch, ed_select_reference_set: whole count matrices in, plain lists out; INTEGRATION.md has the R functions).  Inputs stay R-owned and read-only; outputs are R allocations; the library copies in, launches,
  * synchronises and copies out inside the call (R's API is single-threaded).
  *
  * What it prints is what the reference prints: the mixture notice (src/CNV_estimate.cpp:61) and, for shape parameters
@@ -77,9 +78,179 @@ SEXP C_hmm(SEXP nstates, SEXP nobs, SEXP transitions, SEXP probabilities, SEXP p
   return out;
 }
 
+/* =====================================================================================================================
+ * Cohort-level entries (not in the reference): the per-sample granularity of the two entries above moves ~200 k cells per
+ * call and cannot fill a GPU.  These take the WHOLE count matrices, as R holds them (integer, n_exons x n_samples,
+ * column-major), and return plain lists that the R functions of INTEGRATION.md turn into the reference's objects.  The C
+ * functions carry the prefix edr_ (the C-ABI of libedcore.so owns ed_*); the .Call names are the ones registered below.
+ * ===================================================================================================================== */
+
+static void set_names(SEXP list, const char *const *names, int n)
+{
+  SEXP nm = PROTECT(allocVector(STRSXP, n));
+  for (int i = 0; i < n; i++) SET_STRING_ELT(nm, i, mkChar(names[i]));
+  setAttrib(list, R_NamesSymbol, nm);
+  UNPROTECT(1);
+}
+
+/* CallCNVs for a cohort: per sample what new('ExomeDepth') (R/class_definition.R:82-191: aod::betabin, get_loglike_matrix) and
+ * CallCNVs() (:311-419: C_hmm per chromosome, call decoration :379-405) produce.
+ *   test, reference   integer matrices n_exons x n_samples; exons ordered as CallCNVs orders them (:323-336)
+ *   chrom_off         integer[n_chrom + 1], 0-based first exon of every chromosome (+ n_exons)
+ *   start, end        integer[n_exons]
+ *   tprob, ecl        transition.probability, expected.CNV.length (:261)
+ *   phi, expected     double[n_samples] or NULL (fitted on the device: fit_mode 0 = maximum likelihood, 1 = aod-nm)
+ *   prop_tumor        the mixture (:86, :189)            slab     samples per slab of the pipeline (integer)
+ *   want_path         integer 0/1: also return the Viterbi state of every exon (raw n_exons x n_samples)
+ * Value: list(sample, start.p, end.p, type, nexons, BF, reads.expected, reads.observed, reads.ratio  -- one element per call,
+ *             ordered by (sample, chromosome, position); sample / start.p / end.p 1-based, type 1 = deletion 2 = duplication --
+ *             phi, expected (double[n_samples]), path (raw matrix or NULL), n.unconverged, n.gsl.errors) */
+SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, SEXP end, SEXP tprob, SEXP ecl, SEXP phi,
+                        SEXP expected, SEXP prop_tumor, SEXP slab, SEXP want_path, SEXP fit_mode)
+{
+  const int E = nrows(test), S = ncols(test);
+  if (nrows(reference) != E || ncols(reference) != S) Rf_error("test and reference must be integer matrices of the same shape");
+  if (XLENGTH(start) != E || XLENGTH(end) != E) Rf_error("start and end must have one element per exon");
+  const int C = (int)XLENGTH(chrom_off) - 1;
+  const int given = (phi != R_NilValue);
+  if (given && (expected == R_NilValue || XLENGTH(phi) != S || XLENGTH(expected) != S))
+    Rf_error("phi and expected must both be given, one value per sample");
+  const double mix = REAL(prop_tumor)[0];
+  if (mix != 1) Rprintf("As a warning (this could be normal), the mixture coefficient is %f\n", mix);   /* src/CNV_estimate.cpp:61 */
+  ed_plan *plan = NULL;
+  ed_cohort *co = NULL;
+  if (ed_plan_create(&plan, 0, E, C, INTEGER(chrom_off), INTEGER(start), INTEGER(end), REAL(tprob)[0], REAL(ecl)[0]) != ED_OK)
+    Rf_error("exomedepth_amd: %s", ed_last_error());
+  int sl = INTEGER(slab)[0];
+  if (sl <= 0 || sl > S) sl = S;
+  int rc = ed_cohort_create(&co, plan, sl, 2);
+  if (rc == ED_OK) rc = ed_cohort_set_option(co, "fit_mode", (double)INTEGER(fit_mode)[0]);
+  SEXP out = R_NilValue;
+  int nprot = 0;
+  int64_t n = 0;
+  if (rc == ED_OK) {
+    SEXP rphi = PROTECT(allocVector(REALSXP, S)); nprot++;
+    SEXP rexp = PROTECT(allocVector(REALSXP, S)); nprot++;
+    SEXP rpath = R_NilValue;
+    if (INTEGER(want_path)[0]) { rpath = PROTECT(allocMatrix(RAWSXP, E, S)); nprot++; }
+    rc = ed_cohort_run_host(co, INTEGER(test), INTEGER(reference), S, 1 /* R's column-major */, 4, given ? REAL(phi) : NULL,
+                            given ? REAL(expected) : NULL, mix, REAL(rphi), REAL(rexp), rpath != R_NilValue ? RAW(rpath) : NULL, &n);
+    if (rc == ED_OK) {
+      ed_call *calls = (ed_call *) R_alloc((size_t)(n > 0 ? n : 1), sizeof(ed_call));
+      ed_call_info *info = (ed_call_info *) R_alloc((size_t)(n > 0 ? n : 1), sizeof(ed_call_info));
+      rc = ed_cohort_copy_calls(co, calls, info, n);
+      int64_t nu = 0, ne = 0;
+      if (rc == ED_OK) rc = ed_cohort_run_status(co, &nu, &ne);
+      if (rc == ED_OK) {
+        static const char *const names[] = {"sample", "start.p", "end.p", "type", "nexons", "BF", "reads.expected", "reads.observed",
+                                            "reads.ratio", "phi", "expected", "path", "n.unconverged", "n.gsl.errors"};
+        out = PROTECT(allocVector(VECSXP, 14)); nprot++;
+        SEXP col[9];
+        for (int j = 0; j < 9; j++) {
+          col[j] = allocVector((j == 5 || j == 7 || j == 8) ? REALSXP : INTSXP, (R_xlen_t)n);
+          SET_VECTOR_ELT(out, j, col[j]);                                   /* (protected through `out`) */
+        }
+        for (int64_t i = 0; i < n; i++) {
+          INTEGER(col[0])[i] = calls[i].sample + 1;
+          INTEGER(col[1])[i] = calls[i].start_exon + 1;                    /* start.p after the dummy-exon and shift corrections */
+          INTEGER(col[2])[i] = calls[i].end_exon + 1;                      /* (R/class_definition.R:371-372, :409-410) */
+          INTEGER(col[3])[i] = calls[i].type;
+          INTEGER(col[4])[i] = calls[i].nexons;
+          REAL(col[5])[i] = info[i].BF;                                    /* :404 */
+          INTEGER(col[6])[i] = (info[i].reads_expected > 2147483647LL || info[i].reads_expected < -2147483647LL)
+                                   ? NA_INTEGER : (int)info[i].reads_expected;   /* as.integer(): NA beyond the integer range (:402) */
+          REAL(col[7])[i] = (double)info[i].reads_observed;                /* :397 */
+          REAL(col[8])[i] = info[i].reads_ratio;                           /* :403 */
+        }
+        SET_VECTOR_ELT(out, 9, rphi);
+        SET_VECTOR_ELT(out, 10, rexp);
+        SET_VECTOR_ELT(out, 11, rpath);
+        SEXP rnu = allocVector(INTSXP, 1); SET_VECTOR_ELT(out, 12, rnu); INTEGER(rnu)[0] = (int)nu;
+        SEXP rne = allocVector(INTSXP, 1); SET_VECTOR_ELT(out, 13, rne); INTEGER(rne)[0] = (int)ne;
+        set_names(out, names, 14);
+      }
+    }
+  }
+  if (co) ed_cohort_destroy(co);
+  ed_plan_destroy(plan);
+  UNPROTECT(nprot);
+  if (rc != ED_OK) Rf_error("exomedepth_amd: %s", ed_last_error());
+  return out;
+}
+
+/* The model fit of new('ExomeDepth') alone, for every sample: stands where R/class_definition.R:118 calls
+ * aod::betabin(cbind(test, reference) ~ 1, random = ~ 1) and :168 calls fitted(mod).
+ * Value: list(phi, expected, converged) with one element per sample. */
+SEXP edr_fit_betabin_batch(SEXP test, SEXP reference, SEXP fit_mode)
+{
+  const int E = nrows(test), S = ncols(test);
+  if (nrows(reference) != E || ncols(reference) != S) Rf_error("test and reference must be integer matrices of the same shape");
+  SEXP out = PROTECT(allocVector(VECSXP, 3));
+  SEXP rphi = allocVector(REALSXP, S); SET_VECTOR_ELT(out, 0, rphi);
+  SEXP rexp = allocVector(REALSXP, S); SET_VECTOR_ELT(out, 1, rexp);
+  SEXP rcv = allocVector(INTSXP, S); SET_VECTOR_ELT(out, 2, rcv);
+  const int rc = ed_fit_betabin_host(INTEGER(test), INTEGER(reference), E, S, 1, 4, INTEGER(fit_mode)[0], REAL(rphi), REAL(rexp),
+                                     INTEGER(rcv));
+  if (rc != ED_OK) {
+    UNPROTECT(1);
+    Rf_error("exomedepth_amd: %s", ed_last_error());
+  }
+  static const char *const names[] = {"phi", "expected", "converged"};
+  set_names(out, names, 3);
+  UNPROTECT(1);
+  return out;
+}
+
+/* select.reference.set(test.counts, reference.counts, bin.length, n.bins.reduced) (R/optimize_reference_set.R:53-148), formula ~ 1,
+ * phi.bins = 1.  reference_counts: integer matrix n_bins x n_refs; bin_length: double[n_bins] or NULL.
+ * Value: list(reference.choice = 1-based columns of reference.counts in order of decreasing correlation (:143-145),
+ *             ref.samples (1-based column), correlations, expected.BF, phi, RatioSd, mean.p, median.depth, selected (:104-111),
+ *             n.bins) -- the summary.stats columns one element per reference, in order of decreasing correlation. */
+SEXP edr_select_reference_set(SEXP test_counts, SEXP reference_counts, SEXP bin_length, SEXP n_bins_reduced)
+{
+  const int E = nrows(reference_counts), R = ncols(reference_counts);
+  if (XLENGTH(test_counts) != E)
+    Rf_error("The number of rows of the reference matrix must match the length of the test count data\n");   /* :64 */
+  if (bin_length != R_NilValue && XLENGTH(bin_length) != E) Rf_error("bin.length must have one element per bin");
+  ed_refset_row *rows = (ed_refset_row *) R_alloc((size_t)R, sizeof(ed_refset_row));
+  int32_t n_chosen = 0;
+  int64_t n_sel = 0;
+  const int rc = ed_select_reference_set_host(INTEGER(test_counts), INTEGER(reference_counts), E, R,
+                                              bin_length != R_NilValue ? REAL(bin_length) : NULL, (int64_t)INTEGER(n_bins_reduced)[0],
+                                              rows, &n_chosen, &n_sel);
+  if (rc != ED_OK) Rf_error("exomedepth_amd: %s", ed_last_error());
+  static const char *const names[] = {"reference.choice", "ref.samples", "correlations", "expected.BF", "phi", "RatioSd", "mean.p",
+                                      "median.depth", "selected", "n.bins"};
+  SEXP out = PROTECT(allocVector(VECSXP, 10));
+  SEXP choice = allocVector(INTSXP, n_chosen); SET_VECTOR_ELT(out, 0, choice);
+  for (int i = 0; i < n_chosen; i++) INTEGER(choice)[i] = rows[i].ref_index + 1;
+  SEXP idx = allocVector(INTSXP, R); SET_VECTOR_ELT(out, 1, idx);
+  SEXP col[6];
+  for (int j = 0; j < 6; j++) { col[j] = allocVector(REALSXP, R); SET_VECTOR_ELT(out, 2 + j, col[j]); }
+  SEXP sel = allocVector(INTSXP, R); SET_VECTOR_ELT(out, 8, sel);
+  for (int i = 0; i < R; i++) {
+    INTEGER(idx)[i] = rows[i].ref_index + 1;
+    REAL(col[0])[i] = rows[i].correlation;
+    REAL(col[1])[i] = rows[i].expected_BF;
+    REAL(col[2])[i] = rows[i].phi;
+    REAL(col[3])[i] = rows[i].ratio_sd;
+    REAL(col[4])[i] = rows[i].mean_p;
+    REAL(col[5])[i] = rows[i].median_depth;
+    INTEGER(sel)[i] = rows[i].selected;
+  }
+  SEXP nb = allocVector(REALSXP, 1); SET_VECTOR_ELT(out, 9, nb); REAL(nb)[0] = (double)n_sel;
+  set_names(out, names, 10);
+  UNPROTECT(1);
+  return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {                                /* src/ExomeDepth_init.c:14-18 */
   {"C_hmm",              (DL_FUNC) &C_hmm,              6},
   {"get_loglike_matrix", (DL_FUNC) &get_loglike_matrix, 5},
+  /* cohort-level entries of this library (not in the reference) */
+  {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      13},
+  {"ed_fit_betabin_batch",    (DL_FUNC) &edr_fit_betabin_batch,    3},
+  {"ed_select_reference_set", (DL_FUNC) &edr_select_reference_set, 4},
   {NULL, NULL, 0}
 };
 

@@ -18,11 +18,18 @@ typedef ptrdiff_t R_xlen_t;
 typedef unsigned int SEXPTYPE;
 typedef enum { FALSE = 0, TRUE } Rboolean;
 
+#define CHARSXP 9
 #define INTSXP 13
 #define REALSXP 14
+#define STRSXP 16
 #define VECSXP 19
+#define RAWSXP 24
+#define NA_INTEGER R_NaInt
 
 extern SEXP R_NilValue;
+extern SEXP R_NamesSymbol;
+extern int R_NaInt;
+typedef unsigned char Rbyte;
 
 double *REAL(SEXP x);
 int *INTEGER(SEXP x);
@@ -34,12 +41,27 @@ SEXP Rf_protect(SEXP x);
 void Rf_unprotect(int n);
 SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v);
 SEXP VECTOR_ELT(SEXP x, R_xlen_t i);
+Rbyte *RAW(SEXP x);
+int Rf_nrows(SEXP x);
+int Rf_ncols(SEXP x);
+SEXP Rf_mkChar(const char *s);
+void SET_STRING_ELT(SEXP x, R_xlen_t i, SEXP v);
+SEXP STRING_ELT(SEXP x, R_xlen_t i);
+const char *R_CHAR(SEXP x);
+SEXP Rf_setAttrib(SEXP x, SEXP name, SEXP val);
+SEXP Rf_getAttrib(SEXP x, SEXP name);
 void Rprintf(const char *fmt, ...);
 void Rf_error(const char *fmt, ...) __attribute__((noreturn));
 char *R_alloc(size_t n, int size);
 
 #define allocVector Rf_allocVector
 #define allocMatrix Rf_allocMatrix
+#define nrows Rf_nrows
+#define ncols Rf_ncols
+#define mkChar Rf_mkChar
+#define setAttrib Rf_setAttrib
+#define getAttrib Rf_getAttrib
+#define CHAR(x) R_CHAR(x)
 #define PROTECT(x) Rf_protect(x)
 #define UNPROTECT(n) Rf_unprotect(n)
 

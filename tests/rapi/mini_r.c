@@ -11,9 +11,12 @@
 #include "Rinternals.h"
 #include "R_ext/Rdynload.h"
 
-struct SEXPREC { SEXPTYPE type; R_xlen_t n; int nrow, ncol; void *data; };
-static struct SEXPREC nil_rec = {0, 0, 0, 0, NULL};
+struct SEXPREC { SEXPTYPE type; R_xlen_t n; int nrow, ncol; void *data; SEXP names; };
+static struct SEXPREC nil_rec = {0, 0, 0, 0, NULL, NULL};
+static struct SEXPREC names_sym = {1, 0, 0, 0, NULL, NULL};
 SEXP R_NilValue = &nil_rec;
+SEXP R_NamesSymbol = &names_sym;
+int R_NaInt = (-2147483647 - 1);
 
 static char g_out[1 << 20];
 static size_t g_out_len = 0;
@@ -32,7 +35,7 @@ int LENGTH(SEXP x) { return (int)x->n; }
 SEXP Rf_allocVector(SEXPTYPE type, R_xlen_t length)
 {
   SEXP s = (SEXP)calloc(1, sizeof *s);
-  const size_t el = type == REALSXP ? 8 : (type == INTSXP ? 4 : sizeof(SEXP));
+  const size_t el = type == REALSXP ? 8 : (type == INTSXP ? 4 : ((type == RAWSXP || type == CHARSXP) ? 1 : sizeof(SEXP)));
   s->type = type; s->n = length; s->nrow = (int)length; s->ncol = 1;
   s->data = calloc((size_t)(length > 0 ? length : 1), el);
   return s;
@@ -43,6 +46,20 @@ SEXP Rf_allocMatrix(SEXPTYPE type, int nrow, int ncol)
   s->nrow = nrow; s->ncol = ncol;
   return s;
 }
+Rbyte *RAW(SEXP x) { return (Rbyte *)x->data; }
+int Rf_nrows(SEXP x) { return x->nrow; }
+int Rf_ncols(SEXP x) { return x->ncol; }
+SEXP Rf_mkChar(const char *str)
+{
+  SEXP s = Rf_allocVector(CHARSXP, (R_xlen_t)strlen(str) + 1);
+  memcpy(s->data, str, strlen(str) + 1);
+  return s;
+}
+void SET_STRING_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP *)x->data)[i] = v; }
+SEXP STRING_ELT(SEXP x, R_xlen_t i) { return ((SEXP *)x->data)[i]; }
+const char *R_CHAR(SEXP x) { return (const char *)x->data; }
+SEXP Rf_setAttrib(SEXP x, SEXP name, SEXP val) { if (name == R_NamesSymbol) x->names = val; return val; }
+SEXP Rf_getAttrib(SEXP x, SEXP name) { return (name == R_NamesSymbol && x->names) ? x->names : R_NilValue; }
 SEXP Rf_protect(SEXP x) { if (++g_protect > g_protect_max) g_protect_max = g_protect; return x; }
 void Rf_unprotect(int n) { g_protect -= n; }
 SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP *)x->data)[i] = v; return v; }
@@ -96,6 +113,11 @@ int minir_protect_balance(void) { return g_protect; }
 int minir_protect_max(void) { return g_protect_max; }
 SEXP minir_real(const double *v, R_xlen_t n) { SEXP s = Rf_allocVector(REALSXP, n); if (n) memcpy(s->data, v, (size_t)n * 8); return s; }
 SEXP minir_int(const int *v, R_xlen_t n) { SEXP s = Rf_allocVector(INTSXP, n); if (n) memcpy(s->data, v, (size_t)n * 4); return s; }
+SEXP minir_int_matrix(const int *v, int nrow, int ncol) { SEXP s = minir_int(v, (R_xlen_t)nrow * ncol); s->nrow = nrow; s->ncol = ncol; return s; }
+SEXP minir_nil(void) { return R_NilValue; }
+const char *minir_name(SEXP s, int i) { return (s->names && i < (int)s->names->n) ? R_CHAR(STRING_ELT(s->names, i)) : ""; }
+const unsigned char *minir_raw(SEXP s) { return (const unsigned char *)s->data; }
+const int *minir_int_data(SEXP s) { return (const int *)s->data; }
 int minir_type(SEXP s) { return (int)s->type; }
 int minir_nrow(SEXP s) { return s->nrow; }
 int minir_ncol(SEXP s) { return s->ncol; }
@@ -106,6 +128,26 @@ SEXP minir_call5(void *fn, SEXP a, SEXP b, SEXP c, SEXP d, SEXP e)
   g_protect = 0;
   g_jmp_armed = 1;
   if (setjmp(g_jmp) == 0) r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP))fn)(a, b, c, d, e);
+  g_jmp_armed = 0;
+  return r;
+}
+/* any arity up to 13 (the arities the shim registers) */
+SEXP minir_callv(void *fn, int nargs, SEXP *a)
+{
+  SEXP r = NULL;
+  g_protect = 0;
+  g_jmp_armed = 1;
+  if (setjmp(g_jmp) == 0) {
+    switch (nargs) {
+      case 3: r = ((SEXP (*)(SEXP, SEXP, SEXP))fn)(a[0], a[1], a[2]); break;
+      case 4: r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP))fn)(a[0], a[1], a[2], a[3]); break;
+      case 5: r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP))fn)(a[0], a[1], a[2], a[3], a[4]); break;
+      case 6: r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP))fn)(a[0], a[1], a[2], a[3], a[4], a[5]); break;
+      case 13: r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP))fn)(
+                   a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]); break;
+      default: snprintf(g_err, sizeof g_err, "mini_r: no caller for %d arguments", nargs);
+    }
+  }
   g_jmp_armed = 0;
   return r;
 }

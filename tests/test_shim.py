@@ -55,7 +55,9 @@ def shim():
                             ("minir_protect_balance", C.c_int, []), ("minir_protect_max", C.c_int, []),
                             ("minir_real", vp, [vp, C.c_ssize_t]), ("minir_int", vp, [vp, C.c_ssize_t]),
                             ("minir_type", C.c_int, [vp]), ("minir_nrow", C.c_int, [vp]), ("minir_ncol", C.c_int, [vp]),
-                            ("minir_call5", vp, [vp] * 6), ("minir_call6", vp, [vp] * 7),
+                            ("minir_call5", vp, [vp] * 6), ("minir_call6", vp, [vp] * 7), ("minir_callv", vp, [vp, C.c_int, C.POINTER(vp)]),
+                            ("minir_int_matrix", vp, [vp, C.c_int, C.c_int]), ("minir_nil", vp, []), ("minir_name", C.c_char_p, [vp, C.c_int]),
+                            ("minir_raw", C.POINTER(C.c_ubyte), [vp]), ("minir_int_data", C.POINTER(C.c_int), [vp]),
                             ("REAL", C.POINTER(C.c_double), [vp]), ("XLENGTH", C.c_ssize_t, [vp]), ("VECTOR_ELT", vp, [vp, C.c_ssize_t])):
         fn = getattr(R, name)
         fn.restype, fn.argtypes = res, args
@@ -86,19 +88,58 @@ def shim():
         nargs, fn = entries[name]
         assert len(args) == nargs
         R.minir_reset_output()
-        r = (R.minir_call5 if nargs == 5 else R.minir_call6)(fn, *args)
+        arr = (vp * nargs)(*args)
+        r = R.minir_callv(fn, nargs, arr)
         return r, R.minir_output().decode(), R.minir_error().decode()
-    sh.real, sh.integer, sh.values, sh.dot_call = real, integer, values, dot_call
+
+    def int_matrix(a):                  # an R integer matrix: column-major
+        a = np.asarray(a, dtype=np.int32)
+        f = np.asfortranarray(a)
+        return R.minir_int_matrix(f.ctypes.data, a.shape[0], a.shape[1])
+
+    def as_list(sexp):                  # a named VECSXP -> dict of numpy arrays (REALSXP / INTSXP / RAWSXP / NULL)
+        out = {}
+        for i in range(R.XLENGTH(sexp)):
+            el = R.VECTOR_ELT(sexp, i)
+            name = R.minir_name(sexp, i).decode()
+            t, n = R.minir_type(el), R.XLENGTH(el)
+            if t == 0:
+                out[name] = None
+            elif t == 14:
+                out[name] = values(el)
+            elif t == 13:
+                out[name] = np.ctypeslib.as_array(R.minir_int_data(el), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+            elif t == 24:
+                out[name] = np.ctypeslib.as_array(R.minir_raw(el), shape=(n,)).copy().reshape(R.minir_ncol(el), R.minir_nrow(el)).T
+            else:
+                raise AssertionError("unexpected SEXP type %d" % t)
+        return out
+    sh.real, sh.integer, sh.values, sh.dot_call, sh.int_matrix, sh.as_list, sh.nil = real, integer, values, dot_call, int_matrix, as_list, R.minir_nil()
     return sh
 
 
 def test_registration_is_the_references(shim):
-    """reference src/ExomeDepth_init.c:14-24: {"C_hmm", 6}, {"get_loglike_matrix", 5}, nothing else, dynamic symbols off."""
-    assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5}
-    assert shim.R.minir_n_registered() == 2
+    """reference src/ExomeDepth_init.c:14-24: {"C_hmm", 6}, {"get_loglike_matrix", 5} first and unchanged, dynamic symbols off;
+    next to them the three cohort-level entries of this library."""
+    names = [shim.R.minir_registered_name(i).decode() for i in range(shim.R.minir_n_registered())]
+    assert names[:2] == ["C_hmm", "get_loglike_matrix"]
+    assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5, "ed_call_cnvs_batch": 13,
+                                                          "ed_fit_betabin_batch": 3, "ed_select_reference_set": 4}
     assert shim.R.minir_dynamic_symbols() == 0
-    for name, (_, fn) in shim.entries.items():
-        assert fn == C.cast(getattr(shim.S, name), C.c_void_p).value     # the registered pointers are the exported entries
+    for name in ("C_hmm", "get_loglike_matrix"):
+        assert shim.entries[name][1] == C.cast(getattr(shim.S, name), C.c_void_p).value     # the registered pointers are the exported entries
+    for name, cname in (("ed_call_cnvs_batch", "edr_call_cnvs_batch"), ("ed_fit_betabin_batch", "edr_fit_betabin_batch"),
+                        ("ed_select_reference_set", "edr_select_reference_set")):
+        assert shim.entries[name][1] == C.cast(getattr(shim.S, cname), C.c_void_p).value
+
+
+def test_cohort_entries_check_their_arguments(shim):
+    """shape errors are R errors with a message, before any device work"""
+    t = shim.int_matrix(np.ones((5, 3))); r = shim.int_matrix(np.ones((5, 2)))
+    res, out, err = shim.dot_call("ed_fit_betabin_batch", t, r, shim.integer([0]))
+    assert res is None and "same shape" in err
+    res, out, err = shim.dot_call("ed_select_reference_set", shim.integer([1, 2, 3]), t, shim.nil, shim.integer([0]))
+    assert res is None and err.startswith("The number of rows of the reference matrix must match")
 
 
 def test_shim_texts_are_the_references(shim):
@@ -191,3 +232,110 @@ def test_gsl_error_lines_are_printed_as_the_reference_prints_them(shim, edlib):
     assert np.all(got[1] == 0.0) and np.all(np.isfinite(got))
     one_call = ("ERROR VP_gamma.c 1283 error\n" + HANDLER_LINE) * 3 + "ERROR beta.c 163 gsl_sf_lnbeta_e(x, y, &result)\n" + HANDLER_LINE
     assert out == one_call * 6
+
+
+# ---- the cohort-level entries through SEXPs ----------------------------------------------------------------------
+def _cohort_case(seed=21, E=9000, C_=4, S=150):
+    from exomedepth_amd import synth
+    chrom_off, start, end = synth.exon_design(E, C_, seed=seed)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed=seed, n_segments=4, mean_depth=70.0)
+    return chrom_off, start, end, test, ref, p, phi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("given,slab,mode", [(False, 64, 0), (True, 150, 0), (False, 150, 1)])
+def test_call_cnvs_batch_through_sexp_equals_ctypes_path(shim, edlib, given, slab, mode):
+    """.Call("ed_call_cnvs_batch", ...) on R's column-major integer matrices = the batch interface on the same data, bit for bit:
+    call table, decoration (R/class_definition.R:379-405), fitted parameters, Viterbi path."""
+    chrom_off, start, end, test, ref, p, phi = _cohort_case()
+    E, S = test.shape
+    res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
+                                  shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.real(phi) if given else shim.nil,
+                                  shim.real(p) if given else shim.nil, shim.real([1.0]), shim.integer([slab]), shim.integer([1]), shim.integer([mode]))
+    assert res is not None and err == "" and out == ""
+    got = shim.as_list(res)
+    assert list(got) == ["sample", "start.p", "end.p", "type", "nexons", "BF", "reads.expected", "reads.observed", "reads.ratio", "phi",
+                         "expected", "path", "n.unconverged", "n.gsl.errors"]
+    plan = edlib.Plan(chrom_off, start, end)
+    b = edlib.Batch(plan, S)
+    if mode:
+        from exomedepth_amd._lib import check, lib
+        check(lib().ed_batch_set_fit_mode(b.handle, 1))
+    if given:
+        dphi, dexp = edlib.DeviceArray(phi), edlib.DeviceArray(p)
+    else:
+        dphi, dexp = edlib.DeviceArray(np.zeros(S)), edlib.DeviceArray(np.zeros(S))
+        if slab < S:      # the fit is per sample, but its start values are shared work of a slab: fit slab by slab as the pipeline does
+            fp, fe = np.zeros(S), np.zeros(S)
+            for s0 in range(0, S, slab):
+                n = min(slab, S - s0)
+                bb = edlib.Batch(plan, n)
+                a, c = edlib.DeviceArray(np.zeros(n)), edlib.DeviceArray(np.zeros(n))
+                bb.fit(np.ascontiguousarray(test[:, s0:s0 + n]), np.ascontiguousarray(ref[:, s0:s0 + n]), a, c)
+                edlib.api.check(edlib.api.lib().ed_synchronize(None))
+                fp[s0:s0 + n], fe[s0:s0 + n] = a.to_host(), c.to_host()
+                bb.close()
+            dphi, dexp = edlib.DeviceArray(fp), edlib.DeviceArray(fe)
+        else:
+            b.fit(test, ref, dphi, dexp)
+    b.run(test, ref, dphi, dexp)
+    calls, info = b.calls(), b.call_info()
+    assert np.array_equal(got["sample"], calls["sample"] + 1) and np.array_equal(got["start.p"], calls["start_exon"] + 1)
+    assert np.array_equal(got["end.p"], calls["end_exon"] + 1) and np.array_equal(got["type"], calls["type"])
+    assert np.array_equal(got["nexons"], calls["nexons"]) and len(calls) > 50
+    assert got["BF"].tobytes() == info["BF"].tobytes() and got["reads.ratio"].tobytes() == info["reads_ratio"].tobytes()
+    assert np.array_equal(got["reads.expected"], info["reads_expected"]) and np.array_equal(got["reads.observed"], info["reads_observed"].astype(float))
+    assert got["phi"].tobytes() == dphi.to_host().tobytes() and got["expected"].tobytes() == dexp.to_host().tobytes()
+    assert np.array_equal(got["path"], b.path())                       # raw n_exons x n_samples
+    assert got["n.unconverged"][0] == 0 and got["n.gsl.errors"][0] == 0
+    assert shim.R.minir_protect_balance() == 0
+    b.close(); plan.close()
+
+
+@pytest.mark.gpu
+def test_fit_betabin_batch_through_sexp(shim, edlib, oracle):
+    """.Call("ed_fit_betabin_batch", test, reference, mode): what stands where R/class_definition.R:118 calls aod::betabin.  Mode 0
+    = the maximum-likelihood estimate (against the checker's long-double MLE); mode 1 = aod's own procedure (against the checker's
+    statement-by-statement restatement of R's nmmin on the same objective)."""
+    chrom_off, start, end, test, ref, p, phi = _cohort_case(seed=33, E=6000, S=40)
+    E, S = test.shape
+    for mode in (0, 1):
+        res, out, err = shim.dot_call("ed_fit_betabin_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer([mode]))
+        assert res is not None and err == ""
+        got = shim.as_list(res)
+        assert list(got) == ["phi", "expected", "converged"] and np.all(got["converged"] == 1)
+        for s in (0, 7, 39):
+            if mode == 0:
+                ophi, op, _, _ = oracle.fit_mle(test[:, s], ref[:, s])
+                assert abs(got["phi"][s] - ophi) < 1e-8 * ophi and abs(got["expected"][s] - op) < 1e-8 * op
+            else:
+                ophi, op, ne, fail = oracle.fit_nm(test[:, s], ref[:, s], with_status=True)
+                assert fail == 0
+                # two evaluations of the same objective that differ in the last bits can part ways at a comparison of the search;
+                # both then stop inside optim()'s tolerance region: 1e-3 relative in phi is that region's size
+                assert abs(got["phi"][s] - ophi) < 2e-3 * ophi and abs(got["expected"][s] - op) < 2e-4 * op
+    assert shim.R.minir_protect_balance() == 0
+
+
+@pytest.mark.gpu
+def test_select_reference_set_through_sexp(shim, edlib):
+    """.Call("ed_select_reference_set", test.counts, reference.counts, bin.length, n.bins.reduced) = api.select_reference_set"""
+    rng = np.random.default_rng(4)
+    E, R = 4000, 12
+    lam = rng.lognormal(np.log(90), 0.7, E)
+    noise = np.linspace(0.02, 0.5, R)
+    refs = rng.poisson(lam[:, None] * np.exp(rng.normal(0, noise[None, :], (E, R)))).astype(np.int32)
+    test = rng.poisson(lam).astype(np.int32)
+    bl = rng.integers(80, 400, E).astype(float)
+    want = edlib.select_reference_set(test, refs, bl, 0)
+    res, out, err = shim.dot_call("ed_select_reference_set", shim.integer(test), shim.int_matrix(refs), shim.real(bl), shim.integer([0]))
+    assert res is not None and err == ""
+    got = shim.as_list(res)
+    st = want["summary.stats"]
+    assert np.array_equal(got["ref.samples"], st["ref_index"] + 1)
+    assert [("X%d" % i) for i in got["reference.choice"]] == want["reference.choice"]
+    for a, b in (("correlations", "correlation"), ("expected.BF", "expected_BF"), ("phi", "phi"), ("RatioSd", "ratio_sd"), ("mean.p", "mean_p"),
+                 ("median.depth", "median_depth")):
+        assert got[a].tobytes() == st[b].tobytes(), a
+    assert np.array_equal(got["selected"], st["selected"]) and got["n.bins"][0] == want["n.bins"]
+    assert shim.R.minir_protect_balance() == 0
