@@ -196,17 +196,27 @@ constexpr int kEmitRows = kEmitCells * kEmitBlock / 64;      // exons per workgr
 constexpr int64_t kEmitHeadBlocks = 2048;                    // workgroups of a group's short leading launch (ed_batch_run)
 constexpr int kSideStreams = 3;                              // HIP maps streams onto 4 hardware queues: main + 3
 
+// the portable log's table as a device global: staged into LDS by one load per thread (SGPR base + lane offset)
+__device__ const double k_logt_rows[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+
+// wave-level helpers: a ballot straight from a condition (no 0/1 materialisation) and the rank of a lane inside a mask
+__device__ __forceinline__ unsigned long long ed_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int ed_rank(unsigned long long m)
+{
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ consts,
              const int* __restrict__ cflags, const int64_t* __restrict__ seg, int nseg, int64_t blk_base, int64_t S,
              uint32_t nsb, const double2* __restrict__ tab_gl, const double* __restrict__ tab_lg,
              double* __restrict__ loglik, unsigned long long* __restrict__ nerr, int* __restrict__ cold_flag)
 {
-  __shared__ double t_a[kEmitTasks];   // min (ratio route) or x; overwritten by the result
-  __shared__ double t_b[kEmitTasks];   // max (ratio route) or y
+  __shared__ double t_a[kEmitTasks];   // min(x, y); overwritten by the result
+  __shared__ double t_b[kEmitTasks];   // max(x, y)
   __shared__ double t_r[kEmitTasks];   // min/max
-  __shared__ uint32_t t_i[kEmitTasks]; // where the task's tabulated terms are: index into tab_gl / tab_lg; bit 31: x is the
-                                       // larger argument; 0xffffffff: not tabulated
+  __shared__ uint32_t t_i[kEmitTasks]; // where the task's tabulated terms are: byte offset / 8 into tab_lg (= / 16 into tab_gl);
+                                       // bit 31: x = a1 + obs, the tabulated argument, is the LARGER one; 0xffffffff: not tabulated
   __shared__ double s_logt[ED_PM_LOGT_N * 3];   // the portable log's table (3 KB), see edsf::plog_pos
   __shared__ int n_front, n_back;
   const int tid = threadIdx.x;
@@ -225,7 +235,7 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   {
     const bool has = lane < nseg;
     const int64_t f = has ? seg[3 * lane] : 0, a = has ? seg[3 * lane + 1] : 0, z = has ? seg[3 * lane + 2] : 0;
-    si = __popcll(__ballot(has && f <= blk)) - 1;       // seg[0] = 0 <= blk: at least one
+    si = __popcll(ed_ballot(has && f <= blk)) - 1;       // seg[0] = 0 <= blk: at least one
     if (nseg > 64) while (si + 1 < nseg && seg[3 * (si + 1)] <= blk) ++si;
     if (si < 64) {
       auto pick = [&](int64_t v) {
@@ -260,27 +270,28 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   const int wrow = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t e_first = seg_e0 + (int64_t)eb * kEmitRows + wrow;
   const int64_t s0 = (int64_t)sb * 64;
-  const int64_t s = s0 + lane;
   int slot[kEmitCells * 3];
-  int nflag = 0;
   static_assert(kEmitCells == 1, "the slot allocation below handles one cell per thread");
   // Everything this thread reads from memory is requested here, in one go and ahead of the workgroup's first barrier:
   // the counts (HBM), the per-sample shape parameters and flags (L2) and the logarithm's table (L2) then cost the
   // workgroup ONE exposed latency at its start instead of three in a row.
-  const bool live = (e_first < e_end) && (s < S);
+  const int32_t blk_samples = (int32_t)((S - s0 < 64) ? (S - s0) : 64);
+  const bool row_in = e_first < e_end;                          // scalar
+  const bool live = row_in && (lane < blk_samples);
   // Buffer addressing (SGPR resource + 32-bit lane offset + scalar row offset): no 64-bit vector address arithmetic, and
   // the hardware's range check stands in for predication -- lanes beyond the sample block's end, or a whole wave beyond the
   // segment's last exon, read zeros (and are masked out of the results by `live`).
-  const int32_t blk_samples = (int32_t)((S - s0 < 64) ? (S - s0) : 64);
-  const bool row_in = e_first < e_end;                          // scalar
   const uint32_t l4 = (uint32_t)lane * 4u, l8 = (uint32_t)lane * 8u;
   // streamed once (aux 2 = nt): keep the counts (and the likelihood rows below) from evicting the tables out of L2
   const int32_t obs = __builtin_amdgcn_raw_buffer_load_b32(ed_rsrc(test + (e_first * S + s0), row_in ? blk_samples * 4 : 0), l4, 0, 2);
   const int32_t nref = __builtin_amdgcn_raw_buffer_load_b32(ed_rsrc(ref + (e_first * S + s0), row_in ? blk_samples * 4 : 0), l4, 0, 2);
   // consts [9][S] and flags [3][S]: one resource each from the block's first sample, the row picked by the scalar offset
-  // (rows are S * 8 bytes apart: 9 S * 8 < 2^31 is checked by ed_batch_create)
-  const __amdgpu_buffer_rsrc_t rc = ed_rsrc(consts + s0, (int32_t)((8 * S + blk_samples) * 8));
-  const __amdgpu_buffer_rsrc_t rf = ed_rsrc(cflags + s0, (int32_t)((2 * S + blk_samples) * 4));
+  // (rows are S * 8 bytes apart: 9 S * 8 < 2^31 is checked by ed_batch_create).  The range check covers lane offset +
+  // scalar offset against the resource's size, so lanes beyond the sample block read the NEXT row's first samples on all
+  // rows but the last (d_consts / d_cflags carry 64 elements of padding for that one): harmless -- such lanes are not
+  // `live`, create no task and store nothing.
+  const __amdgpu_buffer_rsrc_t rc = ed_rsrc(consts + s0, (int32_t)((8 * S + 64) * 8));
+  const __amdgpu_buffer_rsrc_t rf = ed_rsrc(cflags + s0, (int32_t)((2 * S + 64) * 4));
   const int32_t rowb = (int32_t)(S * 8);
   double pa1[3], pa2[3];
   int pcf[3];
@@ -292,46 +303,71 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   }
   if (tid == 0) { n_front = 0; n_back = 0; }
   {
-    const double T0[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
-    for (int i = tid; i < ED_PM_LOGT_N * 3; i += kEmitBlock) s_logt[i] = (&T0[0][0])[i];
+    // 384 doubles: one per thread, and a second one for the first half of the threads
+    const double* __restrict__ flat = &k_logt_rows[0][0];
+    const double v0 = flat[tid];
+    const double v1 = (tid < ED_PM_LOGT_N * 3 - kEmitBlock) ? flat[kEmitBlock + tid] : 0.0;
+    s_logt[tid] = v0;
+    if (tid < ED_PM_LOGT_N * 3 - kEmitBlock) s_logt[kEmitBlock + tid] = v1;
   }
+  static_assert(ED_PM_LOGT_N * 3 > kEmitBlock && ED_PM_LOGT_N * 3 <= 2 * kEmitBlock, "two loads per thread cover the table");
   __syncthreads();
   // ---- phase 1: classify and scatter the tasks ----
+  int nflag = 0;
   {
     const int32_t tot = obs + nref;   // as.integer(reference + test), R/class_definition.R:187
+    const double dobs = (double)obs, dtot = (double)tot;
     // A cell without reads: a1 + 0 and (a2 + 0) - 0 are a1 and a2 themselves, so the reference's second log-Beta
     // call repeats the per-sample one bit for bit (same value, same GSL error) -- no task, the result is c - c
     // (exactly +0; NaN if c is not finite).  ~14 % of the exons of the bundled exome data have no reads.
-    const bool empty = live && obs == 0 && tot == 0;
+    const bool empty = live && (obs | tot) == 0;
     const bool work = live && !empty;
-    double tx[3], ty[3], tr[3];
-    unsigned long long mf[3], mb[3];
-    bool cold_any = false;
+    double tmn[3], tmx[3], tr[3];
+    bool xl[3], posv[3];
+    bool inr = true;
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
-      const double x = pa1[st] + (double)obs;                       // src/CNV_estimate.cpp:49
-      const double y = (pa2[st] + (double)tot) - (double)obs;
-      nflag += live ? pcf[st] * (empty ? 2 : 1) : 0;
+      const double x = pa1[st] + dobs;                              // src/CNV_estimate.cpp:49
+      const double y = (pa2[st] + dtot) - dobs;
       const bool pos = (x > 0.0 && y > 0.0);
-      const double mx = (x > y ? x : y);
-      const double mn = (x < y ? x : y);
-      const double rat = mn / mx;
-      const bool front = work && pos && (rat < 0.2);
-      const bool back = work && pos && !front;
+      // both arguments positive numbers (possibly +inf): IEEE minNum / maxNum are the reference's GSL_MIN / GSL_MAX
+      tmn[st] = __builtin_fmin(x, y);
+      tmx[st] = __builtin_fmax(x, y);
+      xl[st] = x > y;
+      posv[st] = pos;
+      inr = inr && (!pos || !work || (tmn[st] >= 1e-100 && tmx[st] <= 1e100));
+    }
+    // min/max: a correctly rounded quotient.  When every task of the wave has 1e-100 <= min <= max <= 1e100 the quotient is a
+    // normal number in [1e-200, 1] and the 8-instruction form gives the bits of '/' (edsf::fdiv); anything else takes '/'.
+    if (ed_ballot(!inr) == 0ull) {
+#pragma unroll
+      for (int st = 0; st < 3; ++st) tr[st] = edsf::fdiv(tmn[st], tmx[st]);
+    } else {
+#pragma unroll
+      for (int st = 0; st < 3; ++st) tr[st] = tmn[st] / tmx[st];
+    }
+    unsigned long long mf[3], mb[3];
+    bool cold_any = false;
+    bool frontv[3];
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      const bool front = work && posv[st] && (tr[st] < 0.2);
+      const bool back = work && posv[st] && !front;
       // A non-positive or NaN argument (phi >= 1, expected outside (0, 1), negative counts) takes the reference's general
       // route through gsl_sf_lngamma_sgn_e's reflection / singular branches: a deep, register-hungry call tree.  This kernel
       // does not contain it (its register allocation would be the callee's: 102 instead of 73, two waves per SIMD lost);
       // such a task is left to k_emit_cold, which runs after the group's launches when this flag is up.
-      const bool cold = work && !pos;
+      const bool cold = work && !posv[st];
       cold_any |= cold;
-      mf[st] = __ballot(front);
-      mb[st] = __ballot(back);
-      tx[st] = x;
-      ty[st] = y;
-      tr[st] = rat;
-      slot[st] = empty ? -2 : (cold ? -3 : (front ? 1 : (back ? 0 : -1)));
+      mf[st] = ed_ballot(front);
+      mb[st] = ed_ballot(back);
+      frontv[st] = front;
+      slot[st] = empty ? -2 : (cold ? -3 : ((front || back) ? 0 : -1));
     }
-    if (cold_any) *cold_flag = 1;
+    // GSL error events of the per-sample constants (rare: one branch for the wave)
+    if (ed_ballot(live && (pcf[0] | pcf[1] | pcf[2]) != 0) != 0ull)
+      nflag = live ? (pcf[0] + pcf[1] + pcf[2]) * (empty ? 2 : 1) : 0;
+    if (ed_ballot(cold_any) != 0ull) { if (cold_any) *cold_flag = 1; }
     // wave-aggregated slot allocation: ONE pair of LDS atomics per wave for its (up to) 192 tasks
     const int nf0 = __popcll(mf[0]), nf1 = __popcll(mf[1]), nb0 = __popcll(mb[0]), nb1 = __popcll(mb[1]);
     int basef = 0, baseb = 0;
@@ -341,23 +377,20 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
     }
     basef = __builtin_amdgcn_readfirstlane(basef);
     baseb = __builtin_amdgcn_readfirstlane(baseb);
-    const unsigned long long below = (1ull << lane) - 1ull;
+    // the task's table entry: (st * kEmitTab + obs) * S + s, in units of one tab_lg element (3 * kEmitTab * S < 2^28, ed_batch_create)
+    const uint32_t ti0 = (uint32_t)obs * (uint32_t)S + (uint32_t)(s0 + lane);
+    const bool in_tab = (unsigned)obs < (unsigned)kEmitTab;
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
-      const int kind = slot[st];   // 1 front, 0 back, < 0 no task
-      if (kind >= 0) {
+      if (slot[st] >= 0) {
         const int offf = basef + (st > 0 ? nf0 : 0) + (st > 1 ? nf1 : 0);
-        const int offb = baseb + (st > 0 ? nb0 : 0) + (st > 1 ? nb1 : 0);
-        const int sl = kind ? offf + __popcll(mf[st] & below) : kEmitTasks - 1 - (offb + __popcll(mb[st] & below));
+        const int offb = (kEmitTasks - 1) - (baseb + (st > 0 ? nb0 : 0) + (st > 1 ? nb1 : 0));
+        const int sl = frontv[st] ? offf + ed_rank(mf[st]) : offb - ed_rank(mb[st]);
         // the gather itself is done by whichever thread evaluates the task: issued at the top of the route, its
-        // result is needed ~100 instructions later, so the latency hides behind the task's own arithmetic
-        // (a task is here only if both arguments are positive; 3 * kEmitTab * S < 2^31 is checked by ed_batch_create)
-        uint32_t ti = ((unsigned)obs < (unsigned)kEmitTab) ? ((uint32_t)(st * kEmitTab + obs) * (uint32_t)S + (uint32_t)s) : 0xffffffffu;
-        const double x = tx[st], y = ty[st];
-        const bool swap = kind && !(x < y);   // ratio route takes (min, max); the general route (x, y)
-        // x = a1 + obs is what is tabulated: bit 31 says that it is the LARGER argument (x == y: its Gamma* serves as Gamma*(mx))
-        if (swap && ti != 0xffffffffu) ti |= 0x80000000u;
-        t_a[sl] = swap ? y : x; t_b[sl] = swap ? x : y; t_r[sl] = tr[st]; t_i[sl] = ti;
+        // result is needed ~100 instructions later, so the latency hides behind the task's own arithmetic.
+        // Both routes only use symmetric expressions of (x, y): the task is (min, max) + which of them x = a1 + obs is
+        uint32_t ti = in_tab ? (ti0 + (uint32_t)(st * kEmitTab) * (uint32_t)S) | (xl[st] ? 0x80000000u : 0u) : 0xffffffffu;
+        t_a[sl] = tmn[st]; t_b[sl] = tmx[st]; t_r[sl] = tr[st]; t_i[sl] = ti;
         slot[st] = sl;
       }
     }
@@ -365,20 +398,30 @@ k_emit_batch(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, 
   __syncthreads();
   // ---- phase 2: evaluate; slots [0,nf) take the ratio route, slots [kEmitTasks-nb, kEmitTasks) the rest ----
   const int nf = n_front, nb = n_back;
+  // the tables through buffer resources: scalar base + 32-bit byte offset (one shift), no 64-bit vector address arithmetic
+  const __amdgpu_buffer_rsrc_t rgl = ed_rsrc(tab_gl, (int32_t)(0x7fffffff));
+  const __amdgpu_buffer_rsrc_t rlg = ed_rsrc(tab_lg, (int32_t)(0x7fffffff));
 #pragma unroll 1
   for (int r = 0; r < kEmitCells * 3; ++r) {
     const int sl = r * kEmitBlock + tid;
     if (sl < nf) {
       const uint32_t ti = t_i[sl];
       double2 gl = make_double2(ed_pm_nan(), ed_pm_nan());
-      if (ti != 0xffffffffu) gl = tab_gl[ti & 0x7fffffffu];
-      if (ti & 0x80000000u) gl.x = -gl.x;
+      if (ti != 0xffffffffu) {
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rgl, (ti & 0x0fffffffu) << 4, 0, 0);
+        gl.x = __hiloint2double((int)q.y, (int)q.x);
+        gl.y = __hiloint2double((int)q.w, (int)q.z);
+      }
+      if (ti & 0x80000000u) gl.x = -gl.x;      // Gamma*(max) handed in (edsf::lnbeta_ratio_pre)
       t_a[sl] = edsf::lnbeta_ratio_pre(t_a[sl], t_b[sl], t_r[sl], gl.x, gl.y, s_logt);
     } else if (sl >= kEmitTasks - nb) {
-      const double x = t_a[sl], y = t_b[sl];
+      const double mn = t_a[sl], mx = t_b[sl];
       const uint32_t ti = t_i[sl];
-      const double lgx = (ti != 0xffffffffu) ? tab_lg[ti] : ed_pm_nan();
-      t_a[sl] = edsf::lnbeta_general_pre(x, y, lgx, s_logt);
+      const bool x_is_max = (ti & 0x80000000u) != 0u;
+      const double lgx = (ti != 0xffffffffu) ? ed_buf_f64(rlg, (ti & 0x0fffffffu) << 3, 0) : ed_pm_nan();
+      // lgamma(x) + lgamma(y) - lgamma(x + y) is symmetric in (x, y) (IEEE addition commutes): x is min or max as the flag says
+      t_a[sl] = edsf::lnbeta_general_pre(x_is_max ? mx : mn, x_is_max ? mn : mx, lgx, s_logt);
     }
   }
   // the per-sample constants of phase 3, requested before the barrier: their latency is spent waiting for the other waves
@@ -1967,9 +2010,9 @@ static hipError_t ed_stream_create(hipStream_t* st, bool own_queue, int device)
 ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples)
 {
   if (!batch || !plan || n_samples <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_create: bad arguments");
-  // 32-bit lane offsets (Viterbi rows, table entries): 3 * kEmitTab * n_samples must stay below 2^31
-  if (n_samples > 500000)
-    return ed_fail(ED_ERR_INVALID, "ed_batch_create: %lld samples in one batch; at most 500000 (split the cohort into batches)",
+  // 32-bit byte offsets into the per-sample tables (3 * kEmitTab * n_samples entries of 16 bytes) and 28-bit entry numbers
+  if (n_samples > 65536)
+    return ed_fail(ED_ERR_INVALID, "ed_batch_create: %lld samples in one batch; at most 65536 (split the cohort into slabs: ed_cohort_*)",
                    (long long)n_samples);
   if (int rc = require_device()) return rc;
   HIP_TRY(hipSetDevice(plan->device));
@@ -1989,10 +2032,10 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   A((void**)&b->d_maps, (size_t)std::max<int64_t>(plan->n_words, 1) * S);
   A((void**)&b->d_ent, (size_t)(plan->n_words / 16 + C + 1) * S * 4);
   A((void**)&b->d_last, (size_t)std::max<int64_t>(C, 1) * S);
-  A((void**)&b->d_consts, (size_t)9 * S * 8);
+  A((void**)&b->d_consts, (size_t)(9 * S + 64) * 8);    // + 64: k_emit_batch's row resources reach one sample block past the last row
   A((void**)&b->d_tab_gl, (size_t)3 * kEmitTab * S * 16);
   A((void**)&b->d_tab_lg, (size_t)3 * kEmitTab * S * 8);
-  A((void**)&b->d_cflags, (size_t)3 * S * 4);
+  A((void**)&b->d_cflags, (size_t)(3 * S + 64) * 4);
   A((void**)&b->d_counts, (size_t)S * std::max<int64_t>(C, 1) * 4);
   A((void**)&b->d_offsets, (size_t)S * std::max<int64_t>(C, 1) * 8);
   A((void**)&b->d_total, 8);

@@ -434,7 +434,7 @@ def test_argument_errors_are_reported_not_crashed(edlib):
     plan = edlib.Plan(chrom_off, start, end)
     with pytest.raises(edlib.EdError):
         edlib.Batch(plan, 0)
-    with pytest.raises(edlib.EdError, match="500000"):
+    with pytest.raises(edlib.EdError, match="65536"):
         edlib.Batch(plan, 600_000)
     batch = edlib.Batch(plan, 3)
     with pytest.raises(edlib.EdError, match="no ed_batch_run"):
