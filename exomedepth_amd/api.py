@@ -847,6 +847,38 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
     return {"reference.choice": choice, "summary.stats": rows, "n.bins": int(n_sel.value)}
 
 
+def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_refs=32, want_reference=True, want_correlations=False):
+    """select.reference.set for every sample of a cohort against all the others (reference vignette/vignette.Rnw:390-402 loop;
+    R/optimize_reference_set.R:53-148 per sample), in one call.
+
+    counts: (E, S) int32 host array or torch CUDA tensor.  Returns dict(n_chosen (S,), choice (S, K) -1 padded,
+    summary.stats (S, K) REFSET_DTYPE, n.bins[, reference: DeviceArray (E, S) aggregate reference][, correlations (S, S)])."""
+    keep = []
+    E, S = int(counts.shape[0]), int(counts.shape[1])
+    if not hasattr(counts, "data_ptr"):
+        counts = _as_r_integer(np.asarray(counts))
+    pc = _device_pointer(counts, np.int32, keep)
+    K = int(min(max_refs if max_refs > 0 else 32, S - 1))
+    bl = _f64(bin_length) if bin_length is not None else None
+    n_chosen = np.zeros(S, dtype=np.int32)
+    choice = np.full((S, K), -1, dtype=np.int32)
+    rows = np.zeros((S, K), dtype=REFSET_DTYPE)
+    corr = np.zeros((S, S)) if want_correlations else None
+    ref = DeviceArray(nbytes=E * S * 4) if want_reference else None
+    if ref is not None:
+        ref.host_dtype, ref.shape = np.dtype(np.int32), (E, S)
+    nsel = C.c_int64(0)
+    check(lib().ed_cohort_select_reference_sets(pc, E, S, _ptr(bl) if bl is not None else None, int(n_bins_reduced), K, _ptr(n_chosen),
+                                                _ptr(choice), _ptr(rows), _ptr(corr) if corr is not None else None,
+                                                ref.ptr if ref is not None else None, C.byref(nsel), None))
+    out = {"n_chosen": n_chosen, "choice": choice, "summary.stats": rows, "n.bins": int(nsel.value)}
+    if ref is not None:
+        out["reference"] = ref
+    if corr is not None:
+        out["correlations"] = corr
+    return out
+
+
 def get_power_betabinom(size, my_phi, my_p, my_alt_p, theory=False, frequentist=False, limit=False):
     """reference R/tools.R:128-166 (vectorised over its arguments): the expected log10 Bayes factor.  theory=True is the
     reference's binomial case (:137-142).  `frequentist` is accepted and ignored, as in the reference (it is never read).

@@ -1254,9 +1254,10 @@ constexpr int kFitQ = 6;            // quantities per partial
 // moments for the starting point: sum y, sum n, sum y^2/n, #cells with n > 0
 __global__ void __launch_bounds__(kWave * kFitSub)
 k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t rrs,
-              int64_t E, int64_t S, int stride, double* __restrict__ partial)
+              int64_t E, int64_t S, int stride, double* __restrict__ partial, int64_t tmod)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const int64_t ts = (tmod ? s % tmod : s) * tcs;   // tmod > 0: column s takes test column s mod tmod (edrefcohort.inc)
   const int sub = threadIdx.y;
   const int64_t chunk = (int64_t)blockIdx.y * kFitSub + sub;
   if (s >= S) return;
@@ -1264,7 +1265,7 @@ k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const 
   const int64_t e1 = min(e0 + kFitChunk / kFitSub, E);
   double sy = 0, sn = 0, syy = 0, cnt = 0;
   for (int64_t e = e0; e < e1; e += stride) {
-    const int y = test[e * trs + s * tcs];   // (trs, tcs) = (S, 1): one column per sample; (1, 0): one shared column
+    const int y = test[e * trs + ts];   // (trs, tcs) = (S, 1): one column per sample; (1, 0): one shared column
     const int n = y + ref[e * rrs + s];
     if (n > 0) {
       sy += (double)y; sn += (double)n;
@@ -1337,9 +1338,10 @@ k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, doubl
 __global__ void __launch_bounds__(kWave * kFitSub)
 k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t rrs,
             int64_t E, int64_t S, int stride, const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
-            double* __restrict__ partial)
+            double* __restrict__ partial, int64_t tmod)
 {
   const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const int64_t ts = (tmod ? s % tmod : s) * tcs;
   const int sub = threadIdx.y;
   const int64_t chunk = (int64_t)blockIdx.y * kFitSub + sub;
   if (s >= S) return;
@@ -1359,7 +1361,7 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
 #pragma unroll
   for (int k = 0; k < kPre; ++k) {
     const int64_t e = e0 + (int64_t)k * stride;
-    yb[k] = (e < e1) ? test[e * trs + s * tcs] : 0;
+    yb[k] = (e < e1) ? test[e * trs + ts] : 0;
     rb[k] = (e < e1) ? ref[e * rrs + s] : 0;
   }
   for (int64_t e = e0; e < e1; e += (int64_t)kPre * stride) {
@@ -1369,7 +1371,7 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
       const int64_t en = e + (int64_t)(kPre + k) * stride;
-      yb[k] = (en < e1) ? test[en * trs + s * tcs] : 0;
+      yb[k] = (en < e1) ? test[en * trs + ts] : 0;
       rb[k] = (en < e1) ? ref[en * rrs + s] : 0;
     }
 #pragma unroll
@@ -2492,7 +2494,8 @@ static void fitwork_free(FitWork* w)
 // use_hist: build count histograms once and iterate on them in one launch (needs one test column per sample laid
 // out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
-                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0, int fit_mode = 0)
+                       int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0, int fit_mode = 0,
+                       int64_t tmod = 0)
 {
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
   const int64_t nch = nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
@@ -2501,7 +2504,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
   // (fit mode 1 starts from aod's glm-binomial intercept logit(sum y / sum n) over ALL exons; the Newton fit only needs a rough start)
-  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial);
+  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial, tmod);
   HIP_TRY(hipMemsetAsync(w.depth, 0, 4, st));
   hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
   if (fit_mode == 1 && !use_hist) return ed_fail(ED_ERR_STATE, "fit mode 1 (aod-nm) works on the count histograms: ed_batch_set_fit_histograms(batch, 0) excludes it");
@@ -2546,11 +2549,11 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
   const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   for (int it = 0; it < coarse; ++it) {
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 16, w.eta, w.lam, w.done, w.partial);
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 16, w.eta, w.lam, w.done, w.partial, tmod);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 0);
   }
   for (int it = 0; it < 10; ++it) {   // converged columns skip their work; typically 3 passes do something
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 1, w.eta, w.lam, w.done, w.partial);
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 1, w.eta, w.lam, w.done, w.partial, tmod);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 1);
   }
   hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
@@ -2809,3 +2812,4 @@ ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
 #include "edbins.inc"
 #include "edcov.inc"
 #include "edcohort.inc"
+#include "edrefcohort.inc"

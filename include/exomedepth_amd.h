@@ -326,6 +326,24 @@ int ed_refset_finalize(ed_refset_row* rows, int64_t n_refs, int32_t* n_chosen);
  * cap of them, *n_positions their number (at most n_reduced + 1).  Host code only (no device needed). */
 int ed_refset_thin_positions(int64_t len, int64_t n_reduced, int64_t* positions, int64_t cap, int64_t* n_positions);
 
+/* select.reference.set for EVERY sample of a cohort at once -- each sample in turn as the test, all the others as candidates,
+ * as the loop of reference vignette/vignette.Rnw:390-402 does -- and the aggregate reference of every sample.
+ *   d_counts   DEVICE int32 [n_bins][n_samples] (sample-minor)       bin_length  HOST double[n_bins] or NULL
+ *   max_refs   K: cumulative references formed per test (0 = 32).  The R loop stops at the first i > 2 with mean.p < 0.05
+ *              (R/optimize_reference_set.R:130), in practice well before 32; a test whose loop would run on is handed to
+ *              ed_select_reference_set (all prefixes), so the result never depends on K -- only a choice LONGER than K is an error
+ *   n_chosen   HOST int32 [n_samples]: which.max(expected.BF) per test (:143-144)
+ *   choice     HOST int32 [n_samples][K]: the chosen references (columns of the cohort) in order of decreasing correlation, -1 padded
+ *   rows       HOST (optional) [n_samples][K]: summary.stats of the first K cumulative references of every test (:104-111)
+ *   correlations HOST (optional) double [n_samples][n_samples]: the correlation matrix of :100 (diagonal 1)
+ *   d_ref_out  DEVICE (optional) int32 [n_bins][n_samples]: aggregate reference = sum of the chosen columns (vignette.Rnw:398-402),
+ *              what ed_batch_run / ed_cohort_submit take as d_ref next to d_test = d_counts
+ * The S x S correlations are one binary64 Gram matrix on the matrix cores (v_mfma_f64_16x16x4_f64); the K x n_samples cumulative
+ * references are fitted as one batch.  Synchronous. */
+int ed_cohort_select_reference_sets(const int32_t* d_counts, int64_t n_bins, int64_t n_samples, const double* bin_length,
+                                    int64_t n_bins_reduced, int32_t max_refs, int32_t* n_chosen, int32_t* choice, ed_refset_row* rows,
+                                    double* correlations, int32_t* d_ref_out, int64_t* n_selected_bins, void* stream);
+
 /* get.power.betabinom(size, my.phi, my.p, my.alt.p) (reference R/tools.R:128-166), default mode (theory = FALSE,
  * frequentist = FALSE, limit = FALSE): the expected log10 Bayes factor sum_{x=0}^{size} dbetabinom(x; alt) log10 BF(x),
  * for n parameter sets at once.  HOST arrays; synchronous. */

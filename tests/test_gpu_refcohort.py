@@ -1,0 +1,94 @@
+"""select.reference.set for every sample of a cohort at once (ed_cohort_select_reference_sets: one binary64 Gram matrix on the
+matrix cores for the S x S correlations, the K x S cumulative references fitted as one batch, the aggregate reference of every sample
+on the device) against S independent calls of the single-test entry -- the loop of reference vignette/vignette.Rnw:390-402 over
+R/optimize_reference_set.R:53-148."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cohort(E=20000, S=64, seed=7, depth=90.0):
+    rng = np.random.default_rng(seed)
+    lam = rng.lognormal(np.log(depth), 0.7, E)
+    sf = rng.lognormal(0, 0.25, S)
+    # samples come in batches of correlated noise (what makes some references better than others)
+    grp = rng.integers(0, 6, S)
+    gnoise = rng.normal(0, 0.12, (E, 6))
+    own = rng.normal(0, 0.05, (E, S))
+    mu = lam[:, None] * sf[None, :] * np.exp(gnoise[:, grp] + own)
+    return rng.poisson(mu).astype(np.int32), rng.integers(80, 600, E).astype(float)
+
+
+@pytest.mark.parametrize("nred", [0, 5000])
+def test_cohort_selection_equals_one_call_per_sample(edlib, nred):
+    counts, bl = _cohort()
+    E, S = counts.shape
+    res = edlib.cohort_select_reference_sets(counts, bl, nred, max_refs=32, want_correlations=True)
+    K = res["choice"].shape[1]
+    agg = res["reference"].to_host().reshape(E, S)
+    n_same = 0
+    for t in range(S):
+        others = np.delete(np.arange(S), t)
+        one = edlib.select_reference_set(counts[:, t], np.ascontiguousarray(counts[:, others]), bl, nred)
+        st = one["summary.stats"]
+        want_choice = [int(others[int(n[1:]) - 1]) for n in one["reference.choice"]]
+        got_choice = [int(v) for v in res["choice"][t, :res["n_chosen"][t]]]
+        assert got_choice == want_choice, (t, got_choice, want_choice)
+        assert res["n.bins"] == one["n.bins"]
+        rows = res["summary.stats"][t]
+        k = min(K, len(st))
+        assert np.array_equal(rows["ref_index"][:k], others[st["ref_index"][:k]])            # the same order of candidates
+        assert np.allclose(rows["correlation"][:k], st["correlation"][:k], rtol=0, atol=1e-12)
+        # statistics of the cumulative references the R loop reaches (NaN beyond its early exit on both sides)
+        for f, tol in (("phi", 1e-7), ("mean_p", 1e-9), ("median_depth", 0), ("ratio_sd", 1e-9), ("expected_BF", 1e-7)):
+            a, b = rows[f][:k], st[f][:k]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (t, f)
+            m = ~np.isnan(a)
+            assert np.allclose(a[m], b[m], rtol=tol, atol=0), (t, f, np.max(np.abs(a[m] - b[m]) / np.abs(b[m])))
+        assert np.array_equal(rows["selected"][:k], st["selected"][:k])
+        assert np.array_equal(agg[:, t], counts[:, want_choice].sum(axis=1))               # the aggregate reference, every exon
+        n_same += 1
+    assert n_same == S
+    c = res["correlations"]
+    assert np.allclose(np.diag(c), 1.0, atol=1e-12) and np.allclose(c, c.T, atol=1e-14)
+    z = counts / (bl[:, None] * counts.sum(axis=0)[None, :] / 1e6)   # all bins: only a sanity check of the scale
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1] - c[0, 1]) < 0.1
+
+
+def test_a_short_max_refs_falls_back_instead_of_changing_the_answer(edlib):
+    """with K = 3 the R loop (which stops at the first i > 2 with mean.p < 0.05) cannot finish inside the K prefixes: every test goes
+    through the single-test entry, and the choices are those of the K = 32 run -- or the call says that a choice does not fit"""
+    counts, bl = _cohort(E=8000, S=24, seed=3)
+    full = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=23, want_reference=False)
+    if full["n_chosen"].max() <= 3:
+        short = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=3, want_reference=False)
+        assert np.array_equal(short["n_chosen"], full["n_chosen"])
+        for t in range(24):
+            assert np.array_equal(short["choice"][t, :short["n_chosen"][t]], full["choice"][t, :full["n_chosen"][t]])
+    else:
+        with pytest.raises(edlib.EdError, match="larger max_refs"):
+            edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=3, want_reference=False)
+
+
+def test_cohort_selection_feeds_the_cohort_pipeline(edlib):
+    """counts -> reference sets -> aggregate reference (device) -> fit + emissions + Viterbi for the whole cohort: the canonical
+    workflow end to end on the device, equal to the batch interface fed the host-built aggregate reference"""
+    from exomedepth_amd import synth
+    counts, bl = _cohort(E=12000, S=48, seed=9)
+    E, S = counts.shape
+    chrom_off, start, end = synth.exon_design(E, 4, seed=2)
+    res = edlib.cohort_select_reference_sets(counts, (end - start) / 1000.0, 5000)
+    plan = edlib.Plan(chrom_off, start, end)
+    co = edlib.Cohort(plan, S, 2)
+    dcounts = edlib.DeviceArray(counts)
+    t = co.submit(dcounts, res["reference"], n_samples=S)
+    got = co.results(t, S, path=True)
+    ref_h = np.stack([counts[:, res["choice"][s, :res["n_chosen"][s]]].sum(axis=1) for s in range(S)], axis=1).astype(np.int32)
+    b = edlib.Batch(plan, S)
+    dphi, dexp = edlib.DeviceArray(np.zeros(S)), edlib.DeviceArray(np.zeros(S))
+    b.fit(counts, ref_h, dphi, dexp)
+    b.run(counts, ref_h, dphi, dexp)
+    assert got["calls"].tobytes() == b.calls().tobytes() and got["path"].tobytes() == b.path().tobytes()
+    assert got["phi"].tobytes() == dphi.to_host().tobytes()
+    b.close(); co.close(); plan.close()
