@@ -1618,6 +1618,8 @@ struct ed_batch {
   int64_t* d_total = nullptr;
   unsigned long long* d_nerr = nullptr;
   ed_call* d_calls = nullptr;
+  uint8_t* d_left_out = nullptr;     // one byte per workgroup of k_emit_bins_tab: a cell was left to the per-cell kernel
+  double* d_ctab = nullptr;          // [3][kBinsRtab][S] lbeta(a1, a2) of the depth-binned model per reference count (edbins.inc)
   ed_call_info* d_info = nullptr;    // decoration of the call table (grown on demand: hipFree would synchronise the device
   int64_t info_cap = 0;              // and with it every other batch of a pipeline)
   struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
@@ -2167,7 +2169,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -2273,7 +2275,13 @@ namespace {
 __global__ void k_emit_bins(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int B, const double* __restrict__ edges,
                             const double* __restrict__ phib, const double* __restrict__ expected, const double* __restrict__ X, int K,
                             const double* __restrict__ beta, double mixture, int64_t E, int64_t S, double* __restrict__ loglik,
-                            unsigned long long* __restrict__ nerr);
+                            unsigned long long* __restrict__ nerr, const double* __restrict__ ctab, int rtab, const uint8_t* __restrict__ left_out);
+__global__ void k_bins_ctab(int B, const double* __restrict__ edges, const double* __restrict__ phib, const double* __restrict__ expected,
+                            double mixture, int64_t S, int rtab, double* __restrict__ ctab);
+__global__ void k_emit_bins_tab(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int B, const double* __restrict__ edges,
+                                const double* __restrict__ phib, const double* __restrict__ expected, double mixture, int64_t E, int64_t S,
+                                const double* __restrict__ ctab, int rtab, double* __restrict__ loglik, uint8_t* __restrict__ left_out);
+constexpr int kBinsRtab = 8192;    // reference counts covered by the table of the depth-binned model's constants (edbins.inc)
 }
 
 // bins > 0: depth-binned dispersion (d_phi = phi.estimates [bins][S], d_edges = complete.bins [(bins + 1)][S])
@@ -2343,11 +2351,25 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       if (!plain && g == 0)   // one launch over every cell; the Viterbi groups follow it
       {
         const int64_t eblk = (E + kEmitBlock / 64 - 1) / (kEmitBlock / 64);   // 4 exons x 64 samples per workgroup
-        hipLaunchKernelGGL(k_emit_bins, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535),
-                                             (unsigned)((eblk + 65534) / 65535)),
+        const dim3 egrid((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535), (unsigned)((eblk + 65534) / 65535));
+        const double* ctab = nullptr;
+        if (bins > 0 && !em.cov) {
+          // depth-binned dispersion: the constants lbeta(a1, a2) per (sample, state, reference count) first, then three tasks per cell
+          if (!b->d_ctab) {
+            if (hipMalloc((void**)&b->d_ctab, (size_t)3 * kBinsRtab * S * 8) != hipSuccess ||
+                hipMalloc((void**)&b->d_left_out, (size_t)egrid.x * egrid.y * egrid.z) != hipSuccess)
+              return ed_fail(ED_ERR_NOMEM, "ed_batch_run_bins: cannot allocate the table of constants");
+          }
+          hipLaunchKernelGGL(k_bins_ctab, dim3((unsigned)((S + 63) / 64), (unsigned)(kBinsRtab / 4)), dim3(256), 0, st, bins, d_edges, d_phi, d_expected,
+                             mixture, S, kBinsRtab, b->d_ctab);
+          hipLaunchKernelGGL(k_emit_bins_tab, egrid, dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S,
+                             b->d_ctab, kBinsRtab, b->d_loglik, b->d_left_out);
+          ctab = b->d_ctab;
+        }
+        hipLaunchKernelGGL(k_emit_bins, egrid,
                            dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, em.cov ? (const double*)nullptr : d_expected, em.X,
                            em.cov ? em.K : -1, em.beta, mixture, E, S, b->d_loglik,
-                           b->d_nerr);
+                           b->d_nerr, ctab, kBinsRtab, b->d_left_out);
       }
       int* cold_flag = reinterpret_cast<int*>(b->d_nerr + 1);
       if (head > 0)
