@@ -31,17 +31,19 @@ def gather_call_tables(local_calls, sample_offset, group=None, dst=0):
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)        # group-local; `dst` is group-local too
+    # gather / send / recv address GLOBAL ranks: translate the group-local ones (identity for the default group)
+    glob = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     dev = local_calls.device
     rows = local_calls.clone()
     if rows.numel():
         rows[:, 0] += int(sample_offset)
     n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)] if rank == dst else None
-    dist.gather(n_local, counts, dst=dst, group=group)
+    dist.gather(n_local, counts, dst=glob(dst), group=group)
     if rank != dst:
         if rows.shape[0]:
-            dist.send(rows.contiguous(), dst=dst, group=group)
+            dist.send(rows.contiguous(), dst=glob(dst), group=group)
         return None
     parts = []
     for r in range(world):
@@ -50,7 +52,7 @@ def gather_call_tables(local_calls, sample_offset, group=None, dst=0):
             parts.append(rows)
         elif c:
             buf = torch.empty((c, 6), dtype=torch.int32, device=dev)
-            dist.recv(buf, src=r, group=group)
+            dist.recv(buf, src=glob(r), group=group)
             parts.append(buf)
     return torch.cat(parts, dim=0) if parts else rows
 

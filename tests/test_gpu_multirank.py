@@ -1,0 +1,48 @@
+"""The N > 1 code path of bench.py on a 1-GPU box: two ranks launched exactly as the driver launches them
+(python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2), both on GPU 0 (ED_BENCH_SHARE_GPU=1), the gather of the
+call tables -- the path's only collective -- over gloo (RCCL refuses two ranks on one device).  Samples are sharded by rank with no
+data-path collective; the gathered table must hold exactly the calls of both shards."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_share_one_gpu_and_gather_their_call_tables(edlib):
+    torch = pytest.importorskip("torch")
+    from exomedepth_amd import synth
+    E, S, C = 20000, 128, 24
+    env = dict(os.environ, ED_BENCH_SHARE_GPU="1", ED_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--exons", str(E), "--samples", str(S), "--cpu-samples", "0", "--verify-columns", "0", "--fit-concordance", "0",
+           "--config1-steps", "0", "--kernel-alone", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["samples_total"] == 2 * S
+    assert d["value"] > 0 and abs(d["value"] - E * S * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    # what the two shards produce, one after the other in this process (the seeds bench.py gives ranks 0 and 1)
+    dev = torch.device("cuda", 0)
+    chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
+    plan = edlib.Plan(chrom_off, start, end, 1e-4, 50000.0)
+    want = 0
+    for rank in (0, 1):
+        torch.manual_seed(20250620 + 3 + rank)      # (bench.py seeds the global generator too: the gamma variates draw from it)
+        test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=20250620 + 3 + 1000 * rank, mean_depth=100.0)
+        b = edlib.Batch(plan, S)
+        dphi = torch.empty(S, dtype=torch.float64, device=dev); dexp = torch.empty(S, dtype=torch.float64, device=dev)
+        b.fit(test, ref, dphi, dexp)
+        b.run(test, ref, dphi, dexp)
+        want += b.n_calls()
+        b.close()
+    plan.close()
+    assert d["n_calls"] == want and want > 0
