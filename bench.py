@@ -301,6 +301,8 @@ def main():
                     "is issued (-1 = the library's default)")
     ap.add_argument("--own-queues", type=int, default=-1, help="cohort driver: 1 = every stream of the pipeline gets a hardware queue of its own, "
                     "0 = ordinary streams (-1 = the library's default, 1)")
+    ap.add_argument("--tables-early", type=int, default=-1, help="cohort driver: 1 = a slab's per-sample constants and tables are made right behind its "
+                    "fit on the fit stream, 0 = at the boundary between two emission launches (-1 = the library's default, 0)")
     ap.add_argument("--stage-inputs", type=int, default=0, help="1: additionally time the same steps with the counts uploaded from pinned host "
                     "memory for every slab (copy stream, double-buffered device slabs): reported as value_with_h2d, never as value")
     ap.add_argument("--wire", type=int, default=2, help="--stage-inputs: bytes per count on the link (2 = uint16 widened on the device, 4 = int32)")
@@ -406,6 +408,8 @@ def main():
             opts["split"] = args.split
         if args.own_queues >= 0:
             opts["own_queues"] = args.own_queues
+        if args.tables_early >= 0:
+            opts["tables_early"] = args.tables_early
         co = ed.Cohort(plan, S, n_batches, **opts)
         batches = []
         last_ticket = [-1]

@@ -1609,6 +1609,7 @@ struct ed_batch {
   std::vector<hipStream_t> sides;       // side streams (groups round-robin): Viterbi overlaps the emissions of later groups
   std::vector<hipEvent_t> job_ev;       // emissions of group g are complete
   std::vector<hipEvent_t> join_ev;      // Viterbi (+ trace-back) of group g is complete
+  hipEvent_t zero_ev = nullptr;         // the call counts have been zeroed (first side stream)
   double* d_consts = nullptr;
   double2* d_tab_gl = nullptr;   // [3][kEmitTab][S] (Gamma*(a1 + obs), log(a1 + obs))   (k_emit_tables)
   double* d_tab_lg = nullptr;    // [3][kEmitTab][S] log Gamma(a1 + obs)
@@ -1634,6 +1635,10 @@ struct ed_batch {
   // Emission launch cut in two (single-group mode only): the first `split_frac` of the workgroups, an event, the rest.  The
   // cohort pipeline (edcohort.inc) makes the NEXT slab's dispersion fit wait for that event, so that the fit is issued --
   // in stream order, whatever the host's timing -- while this slab's emissions are under way.
+  bool prepared = false;                // the per-sample constants and tables of the NEXT run are already made (batch_prepare)
+  const double* prepared_phi = nullptr; // ... from these parameters
+  const double* prepared_exp = nullptr;
+  double prepared_mix = 0.0;
   double split_frac = 0.0;
   hipEvent_t split_ev = nullptr;
   bool split_recorded = false;          // the last run recorded split_ev
@@ -2138,6 +2143,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
     for (auto& e : b->job_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     b->join_ev.resize(n_groups);
     for (auto& e : b->join_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->zero_ev, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void**)&b->d_job_off, joff.size() * 4));
     HIP_TRY(hipMalloc((void**)&b->d_job_chrom, std::max<size_t>(jchr.size(), 1) * 4));
     HIP_TRY(hipMemcpy(b->d_job_off, joff.data(), joff.size() * 4, hipMemcpyHostToDevice));
@@ -2174,6 +2180,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->join_ev) if (e) (void)hipEventDestroy(e);
+  if (b->zero_ev) (void)hipEventDestroy(b->zero_ev);
   for (auto& sd : b->sides) if (sd) (void)hipStreamDestroy(sd);
   if (b->fin) (void)hipStreamDestroy(b->fin);
   if (b->split_ev) (void)hipEventDestroy(b->split_ev);
@@ -2284,6 +2291,24 @@ __global__ void k_emit_bins_tab(const int32_t* __restrict__ test, const int32_t*
 constexpr int kBinsRtab = 8192;    // reference counts covered by the table of the depth-binned model's constants (edbins.inc)
 }
 
+// The per-sample constants (k_sample_consts) and tables (k_emit_tables) of the default model, made AHEAD of ed_batch_run on
+// another stream: they only need (phi, expected), and in the cohort pipeline those come from a fit that finishes in the middle
+// of the previous slab's emission launch -- so the two latency-bound little kernels (0.3 ms) run there instead of standing
+// between two emission launches.  The caller orders `stream_` after the batch's previous emission kernels (they read the
+// tables) and the next ed_batch_run after this work (an event); ed_batch_run then skips the two kernels if it is handed the
+// same parameters.
+static int batch_prepare(ed_batch* b, const double* d_phi, const double* d_expected, double mixture, hipStream_t st)
+{
+  if (b->fused) return ED_OK;
+  const int64_t S = b->S;
+  hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S, b->d_consts, b->d_cflags);
+  hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S, b->d_tab_gl,
+                     b->d_tab_lg);
+  HIP_TRY(hipGetLastError());
+  b->prepared = true; b->prepared_phi = d_phi; b->prepared_exp = d_expected; b->prepared_mix = mixture;
+  return ED_OK;
+}
+
 // bins > 0: depth-binned dispersion (d_phi = phi.estimates [bins][S], d_edges = complete.bins [(bins + 1)][S])
 static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
                           const double* d_expected, double mixture, void* stream_, const EmitModel& em)
@@ -2309,7 +2334,9 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 16, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  if (plain) {
+  const bool ready = plain && b->prepared && b->prepared_phi == d_phi && b->prepared_exp == d_expected && b->prepared_mix == mixture && !b->fused;
+  b->prepared = false;
+  if (plain && !ready) {
     hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
                        b->d_consts, b->d_cflags);
     if (!b->fused)
@@ -2340,7 +2367,13 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
     // Emissions are issued group by group (groups of whole chromosomes, longest chromosomes first); when a
     // group's emissions are done its Viterbi chains start on the side stream and run underneath the
     // VALU-bound emissions of the following groups.  Only the last group's (short) chains are exposed.
-    HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));   // empty chromosomes: no calls
+    // the call counts (atomics of k_tb_paths; empty chromosomes: no calls) are zeroed on the first side stream, after the
+    // first group's emissions: off the caller's stream, where it would stand between two emission launches
+    bool counts_zeroed = false;
+    if (!(b->group_off.size() > 1 && cells > 0)) {
+      HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, st));
+      counts_zeroed = true;
+    }
     for (size_t g = 0; g + 1 < b->group_off.size() && cells > 0; ++g) {
       const int j0 = b->group_off[g], j1 = b->group_off[g + 1];
       // One launch per group, except that a group following another starts with a short separate launch: the
@@ -2399,6 +2432,13 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
       hipStream_t side = b->sides[g % b->sides.size()];
       HIP_TRY(hipStreamWaitEvent(side, b->job_ev[g], 0));
+      if (!counts_zeroed) {   // (g == 0; later groups' trace-backs are ordered after it through their own job events on st)
+        HIP_TRY(hipMemsetAsync(b->d_counts, 0, (size_t)S * std::max<int64_t>(C, 1) * 4, side));
+        HIP_TRY(hipEventRecord(b->zero_ev, side));
+        counts_zeroed = true;
+      } else if (b->sides.size() > 1) {
+        HIP_TRY(hipStreamWaitEvent(side, b->zero_ev, 0));
+      }
       const dim3 gw((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)(j1 - j0));
       hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
                          side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,

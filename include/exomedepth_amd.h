@@ -373,6 +373,8 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *   "own_queues"       1 (default): every stream of the pipeline gets a hardware queue of its own; 0: ordinary streams
  *   "fit_mode"         0 (default) maximum likelihood; 1 aod::betabin's Nelder-Mead procedure (ed_batch_set_fit_mode)
  *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
+ *   "tables_early"     1: a slab's per-sample constants and tables are made right behind its fit, on the fit stream; 0 (default):
+ *                      between two emission launches (the same work either way: measured equal)
  *   "timing"           1: stage times are accumulated (ed_cohort_stage_ms_total); may be switched at any time (resets the sums) */
 typedef struct ed_cohort ed_cohort;
 int ed_cohort_create(ed_cohort** cohort, ed_plan* plan, int64_t slab_samples, int slabs_in_flight);

@@ -7,7 +7,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "anonymous" in r["Kernel
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last three k_emit_batch launches and everything between them
 idx = [i for i, r in enumerate(rows) if "k_emit_batch" in r["Kernel_Name"]]
-a, b = idx[-4], idx[-2]
+a, b = idx[-7], idx[-3]   # (two launches per slab with the cohort pipeline's split: two whole steps)
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
