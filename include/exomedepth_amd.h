@@ -344,6 +344,12 @@ int ed_cohort_select_reference_sets(const int32_t* d_counts, int64_t n_bins, int
                                     int64_t n_bins_reduced, int32_t max_refs, int32_t* n_chosen, int32_t* choice, ed_refset_row* rows,
                                     double* correlations, int32_t* d_ref_out, int64_t* n_selected_bins, void* stream);
 
+/* ... on host data in R's layout: counts the n_bins x n_samples integer matrix, column-major; reference_out_colmajor (optional)
+ * receives the aggregate reference in the same layout.  The other arguments as above. */
+int ed_cohort_select_reference_sets_host(const int32_t* counts_colmajor, int64_t n_bins, int64_t n_samples, const double* bin_length,
+                                         int64_t n_bins_reduced, int32_t max_refs, int32_t* n_chosen, int32_t* choice, ed_refset_row* rows,
+                                         double* correlations, int32_t* reference_out_colmajor, int64_t* n_selected_bins);
+
 /* get.power.betabinom(size, my.phi, my.p, my.alt.p) (reference R/tools.R:128-166), default mode (theory = FALSE,
  * frequentist = FALSE, limit = FALSE): the expected log10 Bayes factor sum_{x=0}^{size} dbetabinom(x; alt) log10 BF(x),
  * for n parameter sets at once.  HOST arrays; synchronous. */

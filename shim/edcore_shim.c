@@ -5,8 +5,8 @@
  *     .Call("get_loglike_matrix", phi, expected, total, observed, mixture)        reference src/CNV_estimate.cpp:16, :52-85
  *     .Call("C_hmm", nstates, nobs, transitions, probabilities, positions, L)     reference src/hmm.cpp:13, :18-167
  * registered exactly as reference src/ExomeDepth_init.c:14-24 registers them ({"C_hmm", 6}, {"get_loglike_matrix", 5},
- * dynamic symbols off) -- plus, next to them, the three cohort-level entries at the end of this file (ed_call_cnvs_batch,
- * ed_fit_betabin_batch, ed_select_reference_set: whole count matrices in, plain lists out; INTEGRATION.md has the R functions).  Inputs stay R-owned and read-only; outputs are R allocations; the library copies in, launches,
+ * dynamic symbols off) -- plus, next to them, the cohort-level entries at the end of this file (ed_call_cnvs_batch,
+ * ed_fit_betabin_batch, ed_select_reference_set, ed_cohort_reference_sets: whole count matrices in, plain lists out; INTEGRATION.md has the R functions).  Inputs stay R-owned and read-only; outputs are R allocations; the library copies in, launches,
  * synchronises and copies out inside the call (R's API is single-threaded).
  *
  * What it prints is what the reference prints: the mixture notice (src/CNV_estimate.cpp:61) and, for shape parameters
@@ -244,6 +244,44 @@ SEXP edr_select_reference_set(SEXP test_counts, SEXP reference_counts, SEXP bin_
   return out;
 }
 
+/* select.reference.set for every sample of a cohort against all the others, and the aggregate reference of every sample: the loop
+ * of vignette/vignette.Rnw:390-402 in one call.  counts: integer matrix n_bins x n_samples; bin_length double[n_bins] or NULL;
+ * n_bins_reduced, max_refs integers.
+ * Value: list(n.chosen integer[n_samples], choice integer matrix max_refs x n_samples (column t: the chosen references of sample t,
+ *             1-based columns of `counts`, in order of decreasing correlation, NA padded), reference integer matrix n_bins x n_samples
+ *             (column t = rowSums of the chosen columns: what new('ExomeDepth', test = counts[, t], reference = reference[, t]) takes),
+ *             correlations double matrix n_samples x n_samples, n.bins) */
+SEXP edr_cohort_reference_sets(SEXP counts, SEXP bin_length, SEXP n_bins_reduced, SEXP max_refs)
+{
+  const int E = nrows(counts), S = ncols(counts);
+  if (S < 2) Rf_error("The reference sequence count data must be provided as a matrix");   /* R/optimize_reference_set.R:63 */
+  if (bin_length != R_NilValue && XLENGTH(bin_length) != E) Rf_error("bin.length must have one element per bin");
+  int K = INTEGER(max_refs)[0];
+  if (K <= 0) K = 32;
+  if (K > S - 1) K = S - 1;
+  SEXP out = PROTECT(allocVector(VECSXP, 5));
+  SEXP nch = allocVector(INTSXP, S); SET_VECTOR_ELT(out, 0, nch);
+  SEXP cho = allocMatrix(INTSXP, K, S); SET_VECTOR_ELT(out, 1, cho);
+  SEXP ref = allocMatrix(INTSXP, E, S); SET_VECTOR_ELT(out, 2, ref);
+  SEXP cor = allocMatrix(REALSXP, S, S); SET_VECTOR_ELT(out, 3, cor);
+  SEXP nb = allocVector(REALSXP, 1); SET_VECTOR_ELT(out, 4, nb);
+  int64_t nsel = 0;
+  /* choice comes back [n_samples][K] row-major = the K x n_samples matrix column-major; correlations are symmetric */
+  const int rc = ed_cohort_select_reference_sets_host(INTEGER(counts), E, S, bin_length != R_NilValue ? REAL(bin_length) : NULL,
+                                                      (int64_t)INTEGER(n_bins_reduced)[0], K, INTEGER(nch), INTEGER(cho), NULL, REAL(cor),
+                                                      INTEGER(ref), &nsel);
+  if (rc != ED_OK) {
+    UNPROTECT(1);
+    Rf_error("exomedepth_amd: %s", ed_last_error());
+  }
+  for (R_xlen_t i = 0; i < (R_xlen_t)K * S; i++) INTEGER(cho)[i] = INTEGER(cho)[i] < 0 ? NA_INTEGER : INTEGER(cho)[i] + 1;
+  REAL(nb)[0] = (double)nsel;
+  static const char *const names[] = {"n.chosen", "choice", "reference", "correlations", "n.bins"};
+  set_names(out, names, 5);
+  UNPROTECT(1);
+  return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {                                /* src/ExomeDepth_init.c:14-18 */
   {"C_hmm",              (DL_FUNC) &C_hmm,              6},
   {"get_loglike_matrix", (DL_FUNC) &get_loglike_matrix, 5},
@@ -251,6 +289,7 @@ static const R_CallMethodDef CallEntries[] = {                                /*
   {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      13},
   {"ed_fit_betabin_batch",    (DL_FUNC) &edr_fit_betabin_batch,    3},
   {"ed_select_reference_set", (DL_FUNC) &edr_select_reference_set, 4},
+  {"ed_cohort_reference_sets", (DL_FUNC) &edr_cohort_reference_sets, 4},
   {NULL, NULL, 0}
 };
 

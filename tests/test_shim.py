@@ -109,6 +109,8 @@ def shim():
                 out[name] = values(el)
             elif t == 13:
                 out[name] = np.ctypeslib.as_array(R.minir_int_data(el), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+                if R.minir_ncol(el) > 1 and R.minir_nrow(el) * R.minir_ncol(el) == n:
+                    out[name] = out[name].reshape(R.minir_ncol(el), R.minir_nrow(el)).T      # column-major matrix
             elif t == 24:
                 out[name] = np.ctypeslib.as_array(R.minir_raw(el), shape=(n,)).copy().reshape(R.minir_ncol(el), R.minir_nrow(el)).T
             else:
@@ -124,12 +126,12 @@ def test_registration_is_the_references(shim):
     names = [shim.R.minir_registered_name(i).decode() for i in range(shim.R.minir_n_registered())]
     assert names[:2] == ["C_hmm", "get_loglike_matrix"]
     assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5, "ed_call_cnvs_batch": 13,
-                                                          "ed_fit_betabin_batch": 3, "ed_select_reference_set": 4}
+                                                          "ed_fit_betabin_batch": 3, "ed_select_reference_set": 4, "ed_cohort_reference_sets": 4}
     assert shim.R.minir_dynamic_symbols() == 0
     for name in ("C_hmm", "get_loglike_matrix"):
         assert shim.entries[name][1] == C.cast(getattr(shim.S, name), C.c_void_p).value     # the registered pointers are the exported entries
     for name, cname in (("ed_call_cnvs_batch", "edr_call_cnvs_batch"), ("ed_fit_betabin_batch", "edr_fit_betabin_batch"),
-                        ("ed_select_reference_set", "edr_select_reference_set")):
+                        ("ed_select_reference_set", "edr_select_reference_set"), ("ed_cohort_reference_sets", "edr_cohort_reference_sets")):
         assert shim.entries[name][1] == C.cast(getattr(shim.S, cname), C.c_void_p).value
 
 
@@ -338,4 +340,27 @@ def test_select_reference_set_through_sexp(shim, edlib):
                  ("median.depth", "median_depth")):
         assert got[a].tobytes() == st[b].tobytes(), a
     assert np.array_equal(got["selected"], st["selected"]) and got["n.bins"][0] == want["n.bins"]
+    assert shim.R.minir_protect_balance() == 0
+
+
+@pytest.mark.gpu
+def test_cohort_reference_sets_through_sexp(shim, edlib):
+    """.Call("ed_cohort_reference_sets", counts, bin.length, n.bins.reduced, max.refs) = api.cohort_select_reference_sets on the same
+    cohort: choices (1-based, NA padded), the aggregate reference matrix in R's layout"""
+    rng = np.random.default_rng(12)
+    E, S = 6000, 20
+    lam = rng.lognormal(np.log(90), 0.7, E)
+    counts = rng.poisson(lam[:, None] * rng.lognormal(0, 0.2, S)[None, :] * np.exp(rng.normal(0, 0.1, (E, S)))).astype(np.int32)
+    bl = rng.integers(80, 400, E).astype(float)
+    want = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=19)
+    res, out, err = shim.dot_call("ed_cohort_reference_sets", shim.int_matrix(counts), shim.real(bl), shim.integer([0]), shim.integer([19]))
+    assert res is not None and err == ""
+    got = shim.as_list(res)
+    assert list(got) == ["n.chosen", "choice", "reference", "correlations", "n.bins"]
+    assert np.array_equal(got["n.chosen"], want["n_chosen"]) and got["n.bins"][0] == want["n.bins"]
+    NA = -2147483648
+    for t in range(S):
+        k = want["n_chosen"][t]
+        assert np.array_equal(got["choice"][:k, t], want["choice"][t, :k] + 1) and np.all(got["choice"][k:, t] == NA)
+    assert np.array_equal(got["reference"], want["reference"].to_host().reshape(E, S))
     assert shim.R.minir_protect_balance() == 0
