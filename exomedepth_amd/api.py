@@ -882,16 +882,15 @@ def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_
 def get_power_betabinom(size, my_phi, my_p, my_alt_p, theory=False, frequentist=False, limit=False):
     """reference R/tools.R:128-166 (vectorised over its arguments): the expected log10 Bayes factor.  theory=True is the
     reference's binomial case (:137-142).  `frequentist` is accepted and ignored, as in the reference (it is never read).
-    limit=True (:145-153) is a Monte-Carlo estimate from 2000 draws of R's random generator: no deterministic counterpart."""
-    if limit and not theory:
-        raise NotImplementedError("get.power.betabinom(limit = TRUE) averages over 2000 draws of R's rbetabinom.ab: "
-                                  "stochastic in the reference, not reproducible without R's generator")
+    limit=True (:145-153) is, in the reference, a Monte-Carlo average over 2000 draws of R's generator; here its expectation
+    (sum over 0 < x < size of dbetabinom.ab(x; alt) times the log10 ratio of the beta densities at x / size): the same quantity
+    without the sampling noise."""
+    mode = 1 if theory else (2 if limit else 0)     # (theory wins, as the reference's two `if` blocks have it)
     size, my_phi, my_p, my_alt_p = np.broadcast_arrays(_f64(np.atleast_1d(size)), _f64(np.atleast_1d(my_phi)),
                                                        _f64(np.atleast_1d(my_p)), _f64(np.atleast_1d(my_alt_p)))
     size, my_phi, my_p, my_alt_p = (_f64(a) for a in (size, my_phi, my_p, my_alt_p))
     out = np.empty(size.size, dtype=np.float64)
-    check(lib().ed_get_power_betabinom_mode(size.size, _ptr(size), _ptr(my_phi), _ptr(my_p), _ptr(my_alt_p),
-                                            1 if theory else 0, _ptr(out)))
+    check(lib().ed_get_power_betabinom_mode(size.size, _ptr(size), _ptr(my_phi), _ptr(my_p), _ptr(my_alt_p), mode, _ptr(out)))
     return out if out.size > 1 else float(out[0])
 
 

@@ -354,9 +354,11 @@ int ed_cohort_select_reference_sets_host(const int32_t* counts_colmajor, int64_t
  * frequentist = FALSE, limit = FALSE): the expected log10 Bayes factor sum_{x=0}^{size} dbetabinom(x; alt) log10 BF(x),
  * for n parameter sets at once.  HOST arrays; synchronous. */
 int ed_get_power_betabinom(int64_t n, const double* size, const double* phi, const double* p, const double* alt_p, double* out);
-/* The same with the reference's `theory` switch: theory != 0 is its binomial case (R/tools.R:137-142), the sum of
- * dbinom(x; size, alt_p) * log10 of the binomial likelihood ratio (phi is not used; 0 < p, alt_p < 1).  `limit = TRUE`
- * (:145-153) draws 2000 random variates from R's generator and has no deterministic counterpart. */
+/* The same with the reference's switches.  mode 1 = `theory = TRUE`, its binomial case (R/tools.R:137-142): the sum of
+ * dbinom(x; size, alt_p) * log10 of the binomial likelihood ratio (phi is not used; 0 < p, alt_p < 1).  mode 2 = `limit = TRUE`
+ * (:145-153): the reference averages log10[dbeta(X/size; alt) / dbeta(X/size; null)] over 2000 draws X ~ rbetabinom.ab(alt) of R's
+ * generator; this entry returns the EXPECTATION that average estimates -- sum_{0 < x < size} dbetabinom.ab(x; alt) * that log ratio --
+ * i.e. the reference's value without its Monte-Carlo noise (standard error ~ sd / sqrt(2000)). */
 int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi, const double* p, const double* alt_p,
                                 int theory, double* out);
 

@@ -109,8 +109,26 @@ def test_get_power_betabinom_standalone(edlib):
     assert abs(got[1]) < 1e-12 and np.allclose(got, exp, rtol=1e-9, atol=1e-12), (got, exp)
     # a binomial separates the hypotheses better than an over-dispersed model of the same means
     assert np.all(got[[0, 2, 3, 4]] > edlib.get_power_betabinom(size[:5], phi[:5], p[:5], alt[:5])[[0, 2, 3, 4]])
-    with pytest.raises(NotImplementedError):
-        edlib.get_power_betabinom(200, 0.1, 0.2, 0.6, limit=True)
+    # limit = TRUE (R/tools.R:145-153): the reference averages log10[dbeta(X/size; alt) / dbeta(X/size; null)] over 2000 draws of
+    # rbetabinom.ab(alt); here the expectation that average estimates, against scipy's beta-binomial pmf and beta log-densities --
+    # and against a seeded Monte-Carlo run of the reference's recipe (2000 draws: agreement within a few standard errors)
+    from scipy import stats
+    got = edlib.get_power_betabinom(size[:5], phi[:5], p[:5], alt[:5], limit=True)
+    rng = np.random.default_rng(5)
+    for k in range(5):
+        n_, f_, q_, a_ = int(size[k]), phi[k], p[k], alt[k]
+        a0, b0 = q_ * (1 - f_) / f_, (1 - q_) * (1 - f_) / f_
+        a1, b1 = a_ * (1 - f_) / f_, (1 - a_) * (1 - f_) / f_
+        x = np.arange(1, n_)
+        w = stats.betabinom.pmf(x, n_, a1, b1)
+        lr = (stats.beta.logpdf(x / n_, a1, b1) - stats.beta.logpdf(x / n_, a0, b0)) * np.log10(np.e)
+        want = float(np.sum(w * lr))
+        assert abs(got[k] - want) <= 1e-8 * max(abs(want), 1e-6), (k, got[k], want)
+        draws = stats.betabinom.rvs(n_, a1, b1, size=2000, random_state=rng) / n_
+        draws = draws[(draws > 0) & (draws < 1)]
+        mc = (stats.beta.logpdf(draws, a1, b1) - stats.beta.logpdf(draws, a0, b0)) * np.log10(np.e)
+        assert abs(mc.mean() - got[k]) < 5 * mc.std() / np.sqrt(len(mc)) + 1e-9, (k, mc.mean(), got[k])
+    assert abs(got[1]) < 1e-12
 
 
 # ---- BASELINE.json configs[4]: select.reference.set, 500 000 bins x 2048 candidate references ----
