@@ -573,20 +573,20 @@ def main():
 
     # ---- after the timed region: the bench checks what it timed, and carries the legs the headline does not -----------------
     verify = None
-    if rank == 0 and args.verify_columns > 0 and plain and not args.fused:
+    if world == 1 and args.verify_columns > 0 and plain and not args.fused:      # (N = 1 only, like cpu_baseline: the other ranks would wait)
         verify = verify_against_oracle(ed, eddist, torch, dev, co if use_cohort else None, batches, last_ticket[0] if use_cohort else None,
                                        n_batches, test, ref, phi, p, phi_fit if not use_cohort else None, p_fit if not use_cohort else None,
                                        bool(args.fit), chrom_off, start, end, args.verify_columns)
     fit_conc = None
-    if rank == 0 and args.fit and plain and not args.fused and args.fit_concordance > 0:
+    if world == 1 and args.fit and plain and not args.fused and args.fit_concordance > 0:
         from exomedepth_amd import concordance
         k = min(args.fit_concordance, S)
         fit_conc = concordance.fit_mode_concordance(plan, test[:, :k].contiguous(), ref[:, :k].contiguous())
     config1 = None
-    if rank == 0 and args.config1_steps > 0 and plain and not args.fused and S >= 64:
+    if world == 1 and args.config1_steps > 0 and plain and not args.fused and S >= 64:
         config1 = config1_leg(ed, torch, plan, test, ref, phi, p, E, args.config1_steps)
     staged = None
-    if rank == 0 and args.stage_inputs and use_cohort:
+    if world == 1 and args.stage_inputs and use_cohort:
         staged = staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
 
     if rank == 0:
