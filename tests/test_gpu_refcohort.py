@@ -92,3 +92,38 @@ def test_cohort_selection_feeds_the_cohort_pipeline(edlib):
     assert got["calls"].tobytes() == b.calls().tobytes() and got["path"].tobytes() == b.path().tobytes()
     assert got["phi"].tobytes() == dphi.to_host().tobytes()
     b.close(); co.close(); plan.close()
+
+
+def test_config4_geometry_every_sample_against_all_others_500k_x_2048(edlib):
+    """BASELINE configs[4]'s geometry at full size -- 500 000 bins x 2048 samples, every sample in turn the test and the other 2047 its
+    candidates (n.bins.reduced = 10 000, as the reference's vignette uses): one call; spot columns against the single-test entry."""
+    torch = pytest.importorskip("torch")
+    import time
+    Eb, S = 500_000, 2048
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    lam = torch.empty(Eb, device=dev, dtype=torch.float32).log_normal_(float(np.log(60.0)), 0.7, generator=g)
+    sig = torch.linspace(0.03, 0.3, S, device=dev)[torch.randperm(S, device=dev, generator=g)]
+    counts = torch.empty((Eb, S), device=dev, dtype=torch.int32)
+    for lo in range(0, Eb, 16384):
+        hi = min(lo + 16384, Eb)
+        noise = torch.exp(torch.randn((hi - lo, S), device=dev, generator=g) * sig[None, :])
+        counts[lo:hi] = torch.poisson(lam[lo:hi, None] * noise, generator=g).to(torch.int32)
+    length = torch.randint(60, 600, (Eb,), device=dev, generator=g).cpu().numpy().astype(np.float64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = edlib.cohort_select_reference_sets(counts, length, 10000, max_refs=32)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("cohort select.reference.set, 500 000 x 2048, n.bins.reduced 10 000: %.3f s, %.1f references chosen on average" % (dt, res["n_chosen"].mean()))
+    assert res["n.bins"] in (10000, 10001) and np.all(res["n_chosen"] >= 1) and np.all(res["n_chosen"] <= 32)
+    ref = res["reference"]
+    from exomedepth_amd import dist as eddist
+    agg = torch.as_tensor(eddist._DevicePointer(ref.ptr.value, (Eb, S), "<i4"), device=dev)
+    for t in (0, 777, 2047):
+        others = torch.cat([counts[:, :t], counts[:, t + 1:]], dim=1).contiguous()
+        one = edlib.select_reference_set(counts[:, t].contiguous(), others, length, 10000)
+        want = [i + (1 if i >= t else 0) for i in [int(n[1:]) - 1 for n in one["reference.choice"]]]
+        assert [int(v) for v in res["choice"][t, :res["n_chosen"][t]]] == want
+        assert torch.equal(agg[:, t], counts[:, want].sum(dim=1).to(torch.int32))
+        del others
