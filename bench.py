@@ -303,8 +303,8 @@ def main():
                     "0 = ordinary streams (-1 = the library's default, 1)")
     ap.add_argument("--tables-early", type=int, default=-1, help="cohort driver: 1 = a slab's per-sample constants and tables are made right behind its "
                     "fit on the fit stream, 0 = at the boundary between two emission launches (-1 = the library's default, 0)")
-    ap.add_argument("--stage-inputs", type=int, default=0, help="1: additionally time the same steps with the counts uploaded from pinned host "
-                    "memory for every slab (copy stream, double-buffered device slabs): reported as value_with_h2d, never as value")
+    ap.add_argument("--stage-inputs", type=int, default=1, help="1 (default, N = 1 only): additionally time the same steps with the counts uploaded from "
+                    "host memory for every slab (copy stream, double-buffered device slabs): reported as value_with_h2d, never as value; 0: skip")
     ap.add_argument("--wire", type=int, default=2, help="--stage-inputs: bytes per count on the link (2 = uint16 widened on the device, 4 = int32)")
     ap.add_argument("--fit-concordance", type=int, default=64, help="columns of the batch on which the whole path is run twice after the timed "
                     "region -- maximum-likelihood fit vs aod::betabin's Nelder-Mead procedure -- and the differences counted (0 = skip)")

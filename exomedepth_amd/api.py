@@ -564,8 +564,7 @@ class Cohort:
         if info:
             out["info"] = b.call_info()
         phi = np.empty(n_samples); exp = np.empty(n_samples)
-        check(lib().ed_memcpy_d2h(_ptr(phi), C.c_void_p(pp), phi.nbytes))
-        check(lib().ed_memcpy_d2h(_ptr(exp), C.c_void_p(pe), exp.nbytes))
+        check(lib().ed_cohort_copy_params(self.handle, int(ticket), _ptr(phi), _ptr(exp)))
         out["phi"], out["expected"] = phi, exp
         if path:
             out["path"] = b.path()

@@ -400,6 +400,8 @@ int ed_cohort_submit(ed_cohort* cohort, const int32_t* d_test, const int32_t* d_
  * ed_batch_path, ...), which wait for that slab only -- and the DEVICE arrays of its (phi, expected).  ED_ERR_STATE once the
  * ticket's slot has been reused. */
 int ed_cohort_batch(ed_cohort* cohort, int64_t ticket, ed_batch** batch, const double** d_phi, const double** d_expected);
+/* that slab's (phi, expected) to HOST arrays [n_samples of the slab] (either may be NULL); waits for that slab only */
+int ed_cohort_copy_params(ed_cohort* cohort, int64_t ticket, double* phi_out, double* expected_out);
 int ed_cohort_wait(ed_cohort* cohort, int64_t ticket);   /* host waits for that slab's call table */
 int ed_cohort_drain(ed_cohort* cohort);                  /* ... for everything submitted so far */
 void* ed_cohort_stream(ed_cohort* cohort);               /* the pipeline's main stream (a hipStream_t) */

@@ -22,7 +22,7 @@ def test_two_ranks_share_one_gpu_and_gather_their_call_tables(edlib):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--exons", str(E), "--samples", str(S), "--cpu-samples", "0", "--verify-columns", "0", "--fit-concordance", "0",
-           "--config1-steps", "0", "--kernel-alone", "0"]
+           "--config1-steps", "0", "--kernel-alone", "0", "--stage-inputs", "0"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
