@@ -149,3 +149,33 @@ def test_stage_ms_reports_the_last_fit_and_run_after_folding(cohort_data):
     ms2 = b.stage_ms()
     assert ms2["fit"] == ms["fit"] and ms2["emissions"] == ms["emissions"]
     b.close()
+
+
+def test_container_to_calls_end_to_end(edlib, tmp_path):
+    """The count-matrix container (EDCOUNT1, exomedepth_amd/io.py -- what stands where getBamCounts' data.frame is,
+    R/countBamInGranges.R:298-370) feeds the pipeline directly: the memory-mapped count block is staged slab by slab through the
+    pinned double buffer (no copy of the file in host memory), the reference sets and aggregate references are made on the device,
+    and the calls equal the batch interface's on the same data."""
+    from exomedepth_amd import io as edio, synth
+    rng = np.random.default_rng(17)
+    E, S = 9000, 96
+    chrom_off, start, end = synth.exon_design(E, 5, seed=4)
+    chromosome = np.repeat([str(c) for c in (3, 1, "X", 2, 7)], np.diff(chrom_off))           # unsorted chromosome labels
+    lam = rng.lognormal(np.log(80.0), 0.7, E)
+    counts = rng.poisson(lam[:, None] * rng.lognormal(0, 0.2, S)[None, :] * np.exp(rng.normal(0, 0.08, (E, S)))).astype(np.int32)
+    path = str(tmp_path / "cohort.edcount")
+    order = edio.write_counts(path, chromosome, start, end, counts)
+    d = edio.read_counts(path, mmap=True)
+    assert d["counts"].shape == (E, S) and np.array_equal(np.asarray(d["counts"]), counts[order])
+    plan = edlib.Plan(d["chrom_off"], d["start"], d["end"])
+    rs = edlib.cohort_select_reference_sets(np.asarray(d["counts"]), (d["end"] - d["start"]) / 1000.0, 3000)
+    ref_h = rs["reference"].to_host().reshape(E, S)
+    co = edlib.Cohort(plan, 40, 2)                                                             # slabs of 40 + 40 + 16 columns of the mapped file
+    out = co.run_host(d["counts"], ref_h, 0, want_path=True)
+    nbytes, _ = co.ingest_stats()
+    assert nbytes == 2 * E * S * 4
+    b = edlib.Batch(plan, S)
+    b.run(np.asarray(d["counts"]), ref_h, out["phi"], out["expected"])
+    assert out["calls"].tobytes() == b.calls().tobytes() and np.array_equal(out["path"], b.path())
+    assert len(out["calls"]) > 0
+    b.close(); co.close(); plan.close()
