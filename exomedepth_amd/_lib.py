@@ -59,6 +59,7 @@ SYMBOLS = [
     ("ed_batch_fit_n_unconverged", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32)]),
     ("ed_batch_fit_subset", C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     ("ed_batch_fit_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    ("ed_batch_fit_bins_form", C.c_int, [_vp]),
     ("ed_batch_run_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     ("ed_batch_phi_linear", C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     ("ed_batch_fit_cov", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),

@@ -295,6 +295,11 @@ class Batch:
         self._keep_run = keep  # keep temporaries alive until the next run
         check(lib().ed_batch_run(self.handle, pt, pr, pp, pe, float(mixture), C.c_void_p(stream or 0)))
 
+    @property
+    def fit_bins_form(self):
+        """form the last fit_bins took: 1 = count histograms, 0 = per cell (set_fit_histograms(0), or data beyond the bins)"""
+        return int(lib().ed_batch_fit_bins_form(self.handle))
+
     def fit_bins(self, test, ref, phi_bins, phi_bins_out, edges_out, expected_out, stream=None):
         """phi.bins > 1 (reference R/class_definition.R:120-147): per sample the depth levels of the reference
         counts (edges_out: (phi_bins + 1, n_samples) complete.bins), one dispersion per level (phi_bins_out:

@@ -1624,6 +1624,8 @@ struct ed_batch {
   ed_call_info* d_info = nullptr;    // decoration of the call table (grown on demand: hipFree would synchronise the device
   int64_t info_cap = 0;              // and with it every other batch of a pipeline)
   struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
+  void* binsw = nullptr;             // workspace of ed_batch_fit_bins' histogram form (BinsWork, edbins_hist.inc)
+  int bins_form = 0;                 // form the last ed_batch_fit_bins took (ed_batch_fit_bins_form)
   int64_t calls_cap = 0;
   hipStream_t stream = nullptr;         // where the results of the last run become available: the caller's stream, or `fin`
   hipStream_t fit_stream = nullptr;     // stream of the last ed_batch_fit (its own timing events only)
@@ -2170,11 +2172,13 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
 }
 
 static void fitwork_free(struct FitWork* w);
+static void binswork_free(void* w);
 
 ED_EXPORT void ed_batch_destroy(ed_batch* b)
 {
   if (!b) return;
   fitwork_free(b->fitw);
+  binswork_free(b->binsw);
   void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);

@@ -166,6 +166,11 @@ int ed_batch_fit_subset(ed_batch* batch, const int32_t* d_test, const int32_t* d
  * Synchronises the stream before returning (the level check is done on the host). */
 int ed_batch_fit_bins(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, int phi_bins, double* d_phi_bins,
                       double* d_edges, double* d_expected, void* stream);
+/* Which form the last ed_batch_fit_bins took: 1 = count histograms (three passes over the counts: unit bins of the reference
+ * counts for the quantile, per-level bins of the test count and of the total for the Newton sums), 0 = per cell on every pass
+ * (what ed_batch_set_fit_histograms(batch, 0) asks for, and what data beyond the bins -- a 0.85 quantile of the reference counts
+ * >= 8192, > 32768 cells of a sample outside its level's bins -- fall back to).  Same estimate to the fit's tolerance. */
+int ed_batch_fit_bins_form(const ed_batch* batch);
 /* ed_batch_run with the per-exon dispersion phi.linear = approxfun(bin mid-points, phi.estimates)(reference)
  * (:141-147) evaluated on the fly; everything downstream of the emissions is ed_batch_run's.  Not available in
  * fused mode. */

@@ -144,3 +144,45 @@ def test_fit_bins_few_exons_per_level(edlib, oracle):
     ophi, op, _, _ = bo.fit_bins(test[:, 0], ref[:, 0], B)
     assert np.max(np.abs(phib[:, 0] - ophi) / ophi) < 1e-6, (phib[:, 0], ophi)
     assert abs(exp[0] - op) / op < 1e-7
+
+
+@pytest.mark.parametrize("B,E,S,depth", [(3, 60000, 21, 90.0), (4, 40000, 9, 150.0), (8, 70001, 5, 60.0), (2, 3000, 3, 40.0)])
+def test_histogram_form_equals_per_cell_form(edlib, B, E, S, depth):
+    """ed_batch_fit_bins on count histograms (csrc/edbins_hist.inc: r bins for the quantile, per-level y and n bins, listed
+    cells) against the per-cell form: complete.bins bit for bit, the estimates to the fit's tolerance"""
+    chrom_off, start, end, test, ref = _case(E, S, 4, 500 + B, depth=depth)
+    plan = edlib.Plan(chrom_off, start, end)
+    out = []
+    for form in (1, 0):
+        batch = edlib.Batch(plan, S)
+        batch.set_fit_histograms(form)
+        d = [edlib.DeviceArray(np.zeros((B, S))), edlib.DeviceArray(np.zeros((B + 1, S))), edlib.DeviceArray(np.zeros(S))]
+        for rep in range(2):                      # the second fit reuses the first one's buffers
+            batch.fit_bins(test, ref, B, *d)
+            assert batch.fit_bins_form == form
+        out.append([x.to_host() for x in d])
+        batch.close()
+    plan.close()
+    (phib, edges, exp), (phib0, edges0, exp0) = out
+    assert np.array_equal(bits(edges), bits(edges0))
+    assert np.max(np.abs(phib - phib0) / phib0) < FIT_REL_TOL
+    assert np.max(np.abs(exp - exp0) / exp0) < FIT_REL_TOL
+
+
+def test_data_beyond_the_bins_take_the_per_cell_form(edlib, oracle):
+    """reference counts whose 0.85 quantile lies beyond the 8192 unit bins: the histogram form declines, the answer is the checker's"""
+    from oracle import bins_oracle as bo
+    E, S, B = 4000, 3, 3
+    chrom_off, start, end, test, ref = _case(E, S, 2, 77, depth=120.0)
+    ref = ref * 40
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S)
+    d = [edlib.DeviceArray(np.zeros((B, S))), edlib.DeviceArray(np.zeros((B + 1, S))), edlib.DeviceArray(np.zeros(S))]
+    batch.fit_bins(test, ref, B, *d)
+    assert batch.fit_bins_form == 0
+    phib, edges, exp = [x.to_host() for x in d]
+    batch.close(); plan.close()
+    for s in range(S):
+        ophi, op, olin, ocomplete = bo.fit_bins(test[:, s], ref[:, s], B)
+        assert np.array_equal(bits(edges[:, s]), bits(ocomplete))
+        assert np.max(np.abs(phib[:, s] - ophi) / ophi) < FIT_REL_TOL
