@@ -68,7 +68,9 @@ def build(force=False, verbose=False):
 VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             # round 1's Horner step (coefficient as an "s" asm operand): contains the VALU-write-SGPR -> VALU-read hazard
             # (tools/isa_hazard_scan.py); built only to demonstrate it on hardware next to the fixed library
-            "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"]}
+            "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"],
+            # k_fit_hist of the shallow geometry with 4 samples per workgroup: half the LDS, emission workgroups fit beside it
+            "fitlight": ["-DED_HG8_WG=4"]}
 
 
 def variant_path(name):

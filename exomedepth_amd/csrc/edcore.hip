@@ -1515,8 +1515,12 @@ __device__ __forceinline__ bool fit_hist_runs(int depth, int launched, int mine)
 
 namespace hg8 {
 #define ED_HG_KS 8
+#ifdef ED_HG8_WG
+#define ED_HG_WG ED_HG8_WG
+#endif
 #include "edfit_hist.inc"
 #undef ED_HG_KS
+#undef ED_HG_WG
 }
 namespace hg4 {
 #define ED_HG_KS 4
@@ -2584,13 +2588,13 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     const int launched = use_hist > 1 ? fit_hist_bit(use_hist) : (hint < 0 ? 7 : fit_hist_bit(fit_hist_geometry(hint)));
     HIP_TRY(hipMemcpyAsync(w.h_depth, w.depth, 4, hipMemcpyDeviceToHost, st));
 #define ED_FIT_HIST(NS, CAP)                                                                                                       \
-    if (launched & fit_hist_bit(NS::kHistSamples))                                                                                 \
+    if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hist, dim3((unsigned)((((S + NS::kHistSamples - 1) / NS::kHistSamples * NS::kHistHalves + 7) / 8) * 8)), \
                          dim3(NS::kHistBlock), 0, st, d_test, d_ref, rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, CAP, w.depth, launched);
     ED_FIT_HIST(hg8, w.cap8) ED_FIT_HIST(hg4, w.cap4) ED_FIT_HIST(hg2, w.cap2)
 #undef ED_FIT_HIST
 #define ED_FIT_NM(NS, CAP)                                                                                                         \
-    if (launched & fit_hist_bit(NS::kHistSamples))                                                                                 \
+    if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnm, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y,     \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 2000 /* optim(control = list(maxit = 2000)) */, d_test, d_ref, rrs,  \
                          E, w.depth, launched, w.fevals);
@@ -2602,7 +2606,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     }
 #undef ED_FIT_NM
 #define ED_FIT_NEWTON(NS, CAP)                                                                                                     \
-    if (launched & fit_hist_bit(NS::kHistSamples))                                                                                 \
+    if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */, \
                          d_test, d_ref, rrs, E, w.depth, launched);
