@@ -99,6 +99,8 @@ SYMBOLS = [
     ("ed_cohort_submit", C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _dbl, _vp, C.POINTER(_i64)]),
     ("ed_cohort_batch", C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     ("ed_cohort_copy_params", C.c_int, [_vp, _i64, _vp, _vp]),
+    ("ed_cohort_copy_bins_params", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    ("ed_cohort_copy_bins", C.c_int, [_vp, _vp, _vp]),
     ("ed_cohort_wait", C.c_int, [_vp, _i64]),
     ("ed_cohort_drain", C.c_int, [_vp]),
     ("ed_cohort_stream", _vp, [_vp]),

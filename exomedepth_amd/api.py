@@ -490,11 +490,14 @@ class Cohort:
         self.handle = C.c_void_p()
         self._keep = {}
         check(lib().ed_cohort_create(C.byref(self.handle), plan.handle, self.slab_samples, self.slabs_in_flight))
+        self.phi_bins = 1
         for k, v in options.items():
             self.set_option(k, v)
 
     def set_option(self, name, value):
         check(lib().ed_cohort_set_option(self.handle, name.encode(), float(value)))
+        if name == "phi_bins":
+            self.phi_bins = int(value)
 
     def close(self):
         if self.handle:
@@ -562,15 +565,23 @@ class Cohort:
         return b, pp.value, pe.value
 
     def results(self, ticket, n_samples, path=False, loglik=False, info=True):
-        """host copies of a ticket's results: dict(calls, info, phi, expected[, path][, loglik])"""
+        """host copies of a ticket's results: dict(calls, info, phi, expected[, path][, loglik]); with the option phi_bins = B > 1
+        phi_bins (B, n) and edges (B + 1, n) stand where phi is"""
         b, pp, pe = self.batch(ticket)
         b.n_samples = int(n_samples)
         out = {"calls": b.calls()}
         if info:
             out["info"] = b.call_info()
-        phi = np.empty(n_samples); exp = np.empty(n_samples)
-        check(lib().ed_cohort_copy_params(self.handle, int(ticket), _ptr(phi), _ptr(exp)))
-        out["phi"], out["expected"] = phi, exp
+        exp = np.empty(n_samples)
+        if self.phi_bins > 1:
+            phib, edges = np.empty((self.phi_bins, n_samples)), np.empty((self.phi_bins + 1, n_samples))
+            check(lib().ed_cohort_copy_bins_params(self.handle, int(ticket), _ptr(phib), _ptr(edges), _ptr(exp)))
+            out["phi_bins"], out["edges"] = phib, edges
+        else:
+            phi = np.empty(n_samples)
+            check(lib().ed_cohort_copy_params(self.handle, int(ticket), _ptr(phi), _ptr(exp)))
+            out["phi"] = phi
+        out["expected"] = exp
         if path:
             out["path"] = b.path()
         if loglik:
@@ -616,6 +627,10 @@ class Cohort:
         nu, ne = C.c_int64(0), C.c_int64(0)
         check(lib().ed_cohort_run_status(self.handle, C.byref(nu), C.byref(ne)))
         out = {"calls": calls, "info": info, "phi": phi_out, "expected": exp_out, "n_unconverged": nu.value, "n_gsl_errors": ne.value}
+        if self.phi_bins > 1:
+            del out["phi"]
+            out["phi_bins"], out["edges"] = np.empty((self.phi_bins, S)), np.empty((self.phi_bins + 1, S))
+            check(lib().ed_cohort_copy_bins(self.handle, _ptr(out["phi_bins"]), _ptr(out["edges"])))
         if want_path:
             out["path"] = path
         return out

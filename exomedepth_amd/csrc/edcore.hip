@@ -2279,6 +2279,8 @@ ED_EXPORT int ed_batch_wait(ed_batch* b, void* stream_)
 struct EmitModel {
   int bins = 0;                   // > 0: d_phi = phi.estimates [bins][S], edges = complete.bins [(bins + 1)][S]
   const double* edges = nullptr;
+  const int* skip = nullptr;      // bins: a device word; non-zero = the parameters are not valid (the fit's histogram form declined, the cohort
+                                  // pipeline will redo the slab): the emission kernels return at once
   bool cov = false;               // true: X [E][K] covariates, beta [K + 1][S] coefficients, d_phi [S]
   int K = 0;
   const double* X = nullptr;
@@ -2290,12 +2292,14 @@ namespace {
 __global__ void k_emit_bins(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int B, const double* __restrict__ edges,
                             const double* __restrict__ phib, const double* __restrict__ expected, const double* __restrict__ X, int K,
                             const double* __restrict__ beta, double mixture, int64_t E, int64_t S, double* __restrict__ loglik,
-                            unsigned long long* __restrict__ nerr, const double* __restrict__ ctab, int rtab, const uint8_t* __restrict__ left_out);
+                            unsigned long long* __restrict__ nerr, const double* __restrict__ ctab, int rtab, const uint8_t* __restrict__ left_out,
+                            const int* __restrict__ skip);
 __global__ void k_bins_ctab(int B, const double* __restrict__ edges, const double* __restrict__ phib, const double* __restrict__ expected,
-                            double mixture, int64_t S, int rtab, double* __restrict__ ctab);
+                            double mixture, int64_t S, int rtab, double* __restrict__ ctab, const int* __restrict__ skip);
 __global__ void k_emit_bins_tab(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int B, const double* __restrict__ edges,
                                 const double* __restrict__ phib, const double* __restrict__ expected, double mixture, int64_t E, int64_t S,
-                                const double* __restrict__ ctab, int rtab, double* __restrict__ loglik, uint8_t* __restrict__ left_out);
+                                const double* __restrict__ ctab, int rtab, double* __restrict__ loglik, uint8_t* __restrict__ left_out,
+                                const int* __restrict__ skip);
 constexpr int kBinsRtab = 8192;    // reference counts covered by the table of the depth-binned model's constants (edbins.inc)
 }
 
@@ -2402,15 +2406,15 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
               return ed_fail(ED_ERR_NOMEM, "ed_batch_run_bins: cannot allocate the table of constants");
           }
           hipLaunchKernelGGL(k_bins_ctab, dim3((unsigned)((S + 63) / 64), (unsigned)(kBinsRtab / 4)), dim3(256), 0, st, bins, d_edges, d_phi, d_expected,
-                             mixture, S, kBinsRtab, b->d_ctab);
+                             mixture, S, kBinsRtab, b->d_ctab, em.skip);
           hipLaunchKernelGGL(k_emit_bins_tab, egrid, dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S,
-                             b->d_ctab, kBinsRtab, b->d_loglik, b->d_left_out);
+                             b->d_ctab, kBinsRtab, b->d_loglik, b->d_left_out, em.skip);
           ctab = b->d_ctab;
         }
         hipLaunchKernelGGL(k_emit_bins, egrid,
                            dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, em.cov ? (const double*)nullptr : d_expected, em.X,
                            em.cov ? em.K : -1, em.beta, mixture, E, S, b->d_loglik,
-                           b->d_nerr, ctab, kBinsRtab, b->d_left_out);
+                           b->d_nerr, ctab, kBinsRtab, b->d_left_out, em.skip);
       }
       int* cold_flag = reinterpret_cast<int*>(b->d_nerr + 1);
       if (head > 0)

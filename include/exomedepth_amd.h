@@ -385,6 +385,13 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *   "split"            fraction of a slab's emission launch after which the NEXT slab's fit is issued (default 0.30; 0 = at once)
  *   "own_queues"       1 (default): every stream of the pipeline gets a hardware queue of its own; 0: ordinary streams
  *   "fit_mode"         0 (default) maximum likelihood; 1 aod::betabin's Nelder-Mead procedure (ed_batch_set_fit_mode)
+ *   "phi_bins"         1 (default): one dispersion per sample; 2..8: the depth-binned dispersion model of the reference's `phi.bins`
+ *                      argument (R/class_definition.R:120-147) for every slab -- ed_batch_fit_bins + ed_batch_run_bins, with the fit on
+ *                      count histograms issued without a host look at its outcome: that is settled when the ticket is first waited
+ *                      for (an empty depth level is that ticket's error, "Binning did not happen properly"; data the histogram form
+ *                      declines are done again through the per-cell form then -- the slab's count arrays must stay in place until
+ *                      the ticket has been waited for).  Parameters cannot be given in this mode; read them with
+ *                      ed_cohort_copy_bins_params / ed_cohort_copy_bins.
  *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
  *   "tables_early"     1: a slab's per-sample constants and tables are made right behind its fit, on the fit stream; 0 (default):
  *                      between two emission launches (the same work either way: measured equal)
@@ -407,6 +414,9 @@ int ed_cohort_submit(ed_cohort* cohort, const int32_t* d_test, const int32_t* d_
 int ed_cohort_batch(ed_cohort* cohort, int64_t ticket, ed_batch** batch, const double** d_phi, const double** d_expected);
 /* that slab's (phi, expected) to HOST arrays [n_samples of the slab] (either may be NULL); waits for that slab only */
 int ed_cohort_copy_params(ed_cohort* cohort, int64_t ticket, double* phi_out, double* expected_out);
+/* option phi_bins > 1: that slab's phi.estimates [phi_bins][n_samples of the slab], complete.bins [(phi_bins + 1)][n_samples] and
+ * fitted(mod) [n_samples] to HOST arrays (any may be NULL) */
+int ed_cohort_copy_bins_params(ed_cohort* cohort, int64_t ticket, double* phi_bins_out, double* edges_out, double* expected_out);
 int ed_cohort_wait(ed_cohort* cohort, int64_t ticket);   /* host waits for that slab's call table */
 int ed_cohort_drain(ed_cohort* cohort);                  /* ... for everything submitted so far */
 void* ed_cohort_stream(ed_cohort* cohort);               /* the pipeline's main stream (a hipStream_t) */
@@ -441,6 +451,9 @@ int ed_cohort_run_host(ed_cohort* cohort, const void* test, const void* ref, int
                        uint8_t* path_out, int64_t* n_calls);
 int ed_cohort_copy_calls(ed_cohort* cohort, ed_call* calls, ed_call_info* info, int64_t cap);
 int ed_cohort_run_status(ed_cohort* cohort, int64_t* n_unconverged, int64_t* n_gsl_errors);
+/* option phi_bins > 1, after ed_cohort_run_host (whose phi_out is not written in that mode): phi.estimates [phi_bins][n_total] and
+ * complete.bins [(phi_bins + 1)][n_total] of the whole cohort */
+int ed_cohort_copy_bins(ed_cohort* cohort, double* phi_bins_out, double* edges_out);
 
 /* The model fit of new('ExomeDepth') alone, for every column of a host-resident cohort: what stands where the reference calls
  * aod::betabin(cbind(test, reference) ~ 1, random = ~ 1) and fitted(mod) (R/class_definition.R:118-119, :168).  layout / wire as

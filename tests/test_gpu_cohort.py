@@ -179,3 +179,97 @@ def test_container_to_calls_end_to_end(edlib, tmp_path):
     assert out["calls"].tobytes() == b.calls().tobytes() and np.array_equal(out["path"], b.path())
     assert len(out["calls"]) > 0
     b.close(); co.close(); plan.close()
+
+
+def _bins_reference(edlib, plan, slabs, B):
+    out = []
+    for test, ref in slabs:
+        n = test.shape[1]
+        b = edlib.Batch(plan, n)
+        d = [edlib.DeviceArray(np.zeros((B, n))), edlib.DeviceArray(np.zeros((B + 1, n))), edlib.DeviceArray(np.zeros(n))]
+        b.fit_bins(test, ref, B, *d)
+        b.run_bins(test, ref, B, *d)
+        out.append({"calls": b.calls().copy(), "info": b.call_info().copy(), "path": b.path().copy(), "loglik": b.loglik().copy(),
+                    "phi_bins": d[0].to_host(), "edges": d[1].to_host(), "expected": d[2].to_host(), "form": b.fit_bins_form})
+        b.close()
+    return out
+
+
+def _bins_check(edlib, plan, slab, B, got, want):
+    """the fit at tolerance (the single-dispersion start of a slab that follows a deeper one sums its histograms in another geometry --
+    an order of summation, DESIGN.md 4.5 -- so the last bits of the estimates depend on the batch object's history), complete.bins bit for
+    bit, and everything downstream bit for bit GIVEN the pipeline's own parameters"""
+    test, ref = slab
+    n = test.shape[1]
+    assert got["edges"].tobytes() == want["edges"].tobytes()
+    assert np.max(np.abs(got["phi_bins"] - want["phi_bins"]) / want["phi_bins"]) < 1e-9
+    assert np.max(np.abs(got["expected"] - want["expected"]) / want["expected"]) < 1e-10
+    b = edlib.Batch(plan, n)
+    b.run_bins(test, ref, B, got["phi_bins"], got["edges"], got["expected"])
+    assert got["calls"].tobytes() == b.calls().tobytes()
+    assert got["info"].tobytes() == b.call_info().tobytes()
+    assert got["path"].tobytes() == b.path().tobytes()
+    assert got["loglik"].tobytes() == b.loglik().tobytes()
+    b.close()
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_depth_binned_model_through_the_cohort(cohort_data, in_flight):
+    """option phi_bins = 3 (the reference's phi.bins, R/class_definition.R:120-147): every slab's grouped fit is issued without a host
+    look at its outcome and settled at the first wait; results are those of ed_batch_fit_bins + ed_batch_run_bins slab by slab.  The third
+    slab's reference counts are scaled beyond the histogram form's bins: that slab is declined on the device and done again per cell."""
+    edlib, plan, slabs, want, S = cohort_data
+    B = 3
+    slabs = [(t, r) for t, r in slabs]
+    slabs[2] = (slabs[2][0], slabs[2][1] * 60)
+    ref_res = _bins_reference(edlib, plan, slabs, B)
+    assert [w["form"] for w in ref_res] == [1, 1, 0, 1, 1]
+    co = edlib.Cohort(plan, S, in_flight, phi_bins=B)
+    dev = [(edlib.DeviceArray(t), edlib.DeviceArray(r)) for t, r in slabs]
+    tickets = []
+    for rounds in range(2):
+        for i, (dt, dr) in enumerate(dev):
+            n = slabs[i][0].shape[1]
+            if len(tickets) >= in_flight:
+                j = len(tickets) - in_flight
+                got = co.results(tickets[j], slabs[j % len(slabs)][0].shape[1], path=True, loglik=True)
+                _bins_check(edlib, plan, slabs[j % len(slabs)], B, got, ref_res[j % len(slabs)])
+            tickets.append(co.submit(dt, dr, n_samples=n))
+    for j in range(len(tickets) - in_flight, len(tickets)):
+        got = co.results(tickets[j], slabs[j % len(slabs)][0].shape[1], path=True, loglik=True)
+        _bins_check(edlib, plan, slabs[j % len(slabs)], B, got, ref_res[j % len(slabs)])
+    with pytest.raises(edlib.EdError):                             # per-sample parameters cannot be given in this mode
+        co.submit(dev[0][0], dev[0][1], phi=edlib.DeviceArray(np.full(S, 0.01)), expected=edlib.DeviceArray(np.full(S, 0.1)))
+    co.close()
+    # the whole cohort from host memory (R's layout)
+    test = np.concatenate([t for t, _ in slabs], axis=1); ref = np.concatenate([r for _, r in slabs], axis=1)
+    co = edlib.Cohort(plan, S, 2, phi_bins=B)
+    out = co.run_host(np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T), 1, want_path=True)
+    co.close()
+    wp = np.concatenate([w["phi_bins"] for w in ref_res], axis=1)
+    assert np.max(np.abs(out["phi_bins"] - wp) / wp) < 1e-9
+    assert np.array_equal(out["edges"], np.concatenate([w["edges"] for w in ref_res], axis=1))
+    b = edlib.Batch(plan, test.shape[1])
+    b.run_bins(test, ref, B, out["phi_bins"], out["edges"], out["expected"])
+    assert np.array_equal(out["path"].T, b.path()) and out["calls"].tobytes() == b.calls().tobytes()
+    b.close()
+
+
+def test_an_empty_depth_level_is_the_error_of_its_ticket(cohort_data):
+    """R/class_definition.R:130-133 through the pipeline: the slab with a constant reference column fails when it is waited for; the
+    slabs around it are unaffected"""
+    edlib, plan, slabs, want, S = cohort_data
+    B = 3
+    bad = slabs[1][1].copy(); bad[:, 7] = 500
+    ref_res = _bins_reference(edlib, plan, [slabs[0], slabs[3]], B)
+    co = edlib.Cohort(plan, S, 2, phi_bins=B)
+    d0 = (edlib.DeviceArray(slabs[0][0]), edlib.DeviceArray(slabs[0][1]))
+    d1 = (edlib.DeviceArray(slabs[1][0]), edlib.DeviceArray(bad))
+    d3 = (edlib.DeviceArray(slabs[3][0]), edlib.DeviceArray(slabs[3][1]))
+    t0 = co.submit(*d0); t1 = co.submit(*d1)
+    _bins_check(edlib, plan, slabs[0], B, co.results(t0, S, path=True, loglik=True), ref_res[0])
+    t2 = co.submit(*d3)
+    with pytest.raises(edlib.EdError, match="Binning did not happen properly"):
+        co.wait(t1)
+    _bins_check(edlib, plan, slabs[3], B, co.results(t2, S, path=True, loglik=True), ref_res[1])
+    co.close()
