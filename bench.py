@@ -394,7 +394,8 @@ def main():
     torch.cuda.synchronize()
     plan = ed.Plan(chrom_off, start, end, 1e-4, 50000.0, device=local_rank)
     plain = args.cov == 0 and args.phi_bins == 1
-    use_cohort = args.driver == "cohort" and plain and not args.fused
+    bins_cohort = args.driver == "cohort" and args.cov == 0 and args.phi_bins > 1 and args.fit and not args.fused
+    use_cohort = args.driver == "cohort" and (plain or bins_cohort) and not args.fused
     step_no = [0]
     if use_cohort:
         # The library's cohort pipeline: every step is ONE submission (ed_cohort_submit); the library owns the streams, rotates
@@ -410,6 +411,10 @@ def main():
             opts["own_queues"] = args.own_queues
         if args.tables_early >= 0:
             opts["tables_early"] = args.tables_early
+        if bins_cohort:
+            opts["phi_bins"] = args.phi_bins          # the depth-binned model through the same pipeline (option phi_bins)
+            if os.environ.get("ED_BENCH_BINS_PIECES"):
+                opts["bins_pieces"] = int(os.environ["ED_BENCH_BINS_PIECES"])
         co = ed.Cohort(plan, S, n_batches, **opts)
         batches = []
         last_ticket = [-1]

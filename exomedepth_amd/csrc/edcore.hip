@@ -1630,6 +1630,7 @@ struct ed_batch {
   struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
   void* binsw = nullptr;             // workspace of ed_batch_fit_bins' histogram form (BinsWork, edbins_hist.inc)
   int bins_form = 0;                 // form the last ed_batch_fit_bins took (ed_batch_fit_bins_form)
+  int bins_pieces = 1;               // launches the depth-binned emission kernel is cut into (the cohort pipeline sets it)
   int64_t calls_cap = 0;
   hipStream_t stream = nullptr;         // where the results of the last run become available: the caller's stream, or `fin`
   hipStream_t fit_stream = nullptr;     // stream of the last ed_batch_fit (its own timing events only)
@@ -2299,7 +2300,7 @@ __global__ void k_bins_ctab(int B, const double* __restrict__ edges, const doubl
 __global__ void k_emit_bins_tab(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int B, const double* __restrict__ edges,
                                 const double* __restrict__ phib, const double* __restrict__ expected, double mixture, int64_t E, int64_t S,
                                 const double* __restrict__ ctab, int rtab, double* __restrict__ loglik, uint8_t* __restrict__ left_out,
-                                const int* __restrict__ skip);
+                                const int* __restrict__ skip, int64_t blk0, int64_t nblk);
 constexpr int kBinsRtab = 8192;    // reference counts covered by the table of the depth-binned model's constants (edbins.inc)
 }
 
@@ -2407,8 +2408,17 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
           }
           hipLaunchKernelGGL(k_bins_ctab, dim3((unsigned)((S + 63) / 64), (unsigned)(kBinsRtab / 4)), dim3(256), 0, st, bins, d_edges, d_phi, d_expected,
                              mixture, S, kBinsRtab, b->d_ctab, em.skip);
-          hipLaunchKernelGGL(k_emit_bins_tab, egrid, dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S,
-                             b->d_ctab, kBinsRtab, b->d_loglik, b->d_left_out, em.skip);
+          // In the cohort pipeline the launch is cut into pieces: the NEXT slab's fit consists of several kernels whose workgroups need a
+          // (nearly) whole CU each, and such a workgroup only gets one at a launch boundary, where the CUs drain -- under one uncut
+          // launch the 3.5-ms fit took the launch's whole 13.8 ms and then stood between two emission launches.
+          const int pieces = (int)std::max<int64_t>(1, std::min<int64_t>(b->bins_pieces, eblk));
+          for (int pc = 0; pc < pieces; ++pc) {
+            const int64_t pb0 = eblk * pc / pieces, pb1 = eblk * (pc + 1) / pieces, pn = pb1 - pb0;
+            if (pn <= 0) continue;
+            const dim3 pgrid((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(pn, 65535), (unsigned)((pn + 65534) / 65535));
+            hipLaunchKernelGGL(k_emit_bins_tab, pgrid, dim3(kEmitBlock), 0, st, d_test, d_ref, bins, d_edges, d_phi, d_expected, mixture, E, S,
+                               b->d_ctab, kBinsRtab, b->d_loglik, b->d_left_out, em.skip, pb0, pn);
+          }
           ctab = b->d_ctab;
         }
         hipLaunchKernelGGL(k_emit_bins, egrid,

@@ -392,6 +392,8 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *                      declines are done again through the per-cell form then -- the slab's count arrays must stay in place until
  *                      the ticket has been waited for).  Parameters cannot be given in this mode; read them with
  *                      ed_cohort_copy_bins_params / ed_cohort_copy_bins.
+ *   "bins_pieces"      phi_bins > 1, pipelined: launches the emission kernel of a slab is cut into (default 10): the next slab's fit is
+ *                      a chain of kernels whose workgroups need a whole CU each and only get one where a launch ends
  *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
  *   "tables_early"     1: a slab's per-sample constants and tables are made right behind its fit, on the fit stream; 0 (default):
  *                      between two emission launches (the same work either way: measured equal)
