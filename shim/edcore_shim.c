@@ -102,12 +102,17 @@ static void set_names(SEXP list, const char *const *names, int n)
  *   phi, expected     double[n_samples] or NULL (fitted on the device: fit_mode 0 = maximum likelihood, 1 = aod-nm)
  *   prop_tumor        the mixture (:86, :189)            slab     samples per slab of the pipeline (integer)
  *   want_path         integer 0/1: also return the Viterbi state of every exon (raw n_exons x n_samples)
+ *   phi_bins          the reference's phi.bins (R/class_definition.R:86, :120-147): 1 = one dispersion per sample; 2..8 = one per depth
+ *                     level of the reference counts, phi.linear interpolated per exon (phi / expected cannot be given then)
  * Value: list(sample, start.p, end.p, type, nexons, BF, reads.expected, reads.observed, reads.ratio  -- one element per call,
  *             ordered by (sample, chromosome, position); sample / start.p / end.p 1-based, type 1 = deletion 2 = duplication --
- *             phi, expected (double[n_samples]), path (raw matrix or NULL), n.unconverged, n.gsl.errors) */
+ *             phi, expected (double[n_samples]), path (raw matrix or NULL), n.unconverged, n.gsl.errors,
+ *             phi.bins (phi_bins x n_samples: phi.estimates per level; NULL for phi_bins = 1; `phi` is NA then),
+ *             complete.bins ((phi_bins + 1) x n_samples: the level edges, :125-126; NULL for phi_bins = 1)) */
 SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, SEXP end, SEXP tprob, SEXP ecl, SEXP phi,
-                        SEXP expected, SEXP prop_tumor, SEXP slab, SEXP want_path, SEXP fit_mode)
+                        SEXP expected, SEXP prop_tumor, SEXP slab, SEXP want_path, SEXP fit_mode, SEXP phi_bins)
 {
+  const int B = INTEGER(phi_bins)[0];
   const int E = nrows(test), S = ncols(test);
   if (nrows(reference) != E || ncols(reference) != S) Rf_error("test and reference must be integer matrices of the same shape");
   if (XLENGTH(start) != E || XLENGTH(end) != E) Rf_error("start and end must have one element per exon");
@@ -115,6 +120,8 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
   const int given = (phi != R_NilValue);
   if (given && (expected == R_NilValue || XLENGTH(phi) != S || XLENGTH(expected) != S))
     Rf_error("phi and expected must both be given, one value per sample");
+  if (B < 1 || B > 8) Rf_error("phi.bins must be in 1..8");
+  if (B > 1 && given) Rf_error("with phi.bins > 1 the dispersions are fitted per depth level: phi and expected cannot be given");
   const double mix = REAL(prop_tumor)[0];
   if (mix != 1) Rprintf("As a warning (this could be normal), the mixture coefficient is %f\n", mix);   /* src/CNV_estimate.cpp:61 */
   ed_plan *plan = NULL;
@@ -125,6 +132,7 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
   if (sl <= 0 || sl > S) sl = S;
   int rc = ed_cohort_create(&co, plan, sl, 2);
   if (rc == ED_OK) rc = ed_cohort_set_option(co, "fit_mode", (double)INTEGER(fit_mode)[0]);
+  if (rc == ED_OK && B > 1) rc = ed_cohort_set_option(co, "phi_bins", (double)B);
   SEXP out = R_NilValue;
   int nprot = 0;
   int64_t n = 0;
@@ -143,8 +151,9 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
       if (rc == ED_OK) rc = ed_cohort_run_status(co, &nu, &ne);
       if (rc == ED_OK) {
         static const char *const names[] = {"sample", "start.p", "end.p", "type", "nexons", "BF", "reads.expected", "reads.observed",
-                                            "reads.ratio", "phi", "expected", "path", "n.unconverged", "n.gsl.errors"};
-        out = PROTECT(allocVector(VECSXP, 14)); nprot++;
+                                            "reads.ratio", "phi", "expected", "path", "n.unconverged", "n.gsl.errors", "phi.bins",
+                                            "complete.bins"};
+        out = PROTECT(allocVector(VECSXP, 16)); nprot++;
         SEXP col[9];
         for (int j = 0; j < 9; j++) {
           col[j] = allocVector((j == 5 || j == 7 || j == 8) ? REALSXP : INTSXP, (R_xlen_t)n);
@@ -167,7 +176,23 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
         SET_VECTOR_ELT(out, 11, rpath);
         SEXP rnu = allocVector(INTSXP, 1); SET_VECTOR_ELT(out, 12, rnu); INTEGER(rnu)[0] = (int)nu;
         SEXP rne = allocVector(INTSXP, 1); SET_VECTOR_ELT(out, 13, rne); INTEGER(rne)[0] = (int)ne;
-        set_names(out, names, 14);
+        SET_VECTOR_ELT(out, 14, R_NilValue);
+        SET_VECTOR_ELT(out, 15, R_NilValue);
+        if (B > 1) {
+          /* [level][sample] row-major on the library's side = the n_samples x levels matrix column-major: transposed here */
+          double *pb = (double *) R_alloc((size_t)B * S, sizeof(double)), *eb = (double *) R_alloc((size_t)(B + 1) * S, sizeof(double));
+          rc = ed_cohort_copy_bins(co, pb, eb);
+          if (rc == ED_OK) {
+            SEXP rpb = allocMatrix(REALSXP, B, S); SET_VECTOR_ELT(out, 14, rpb);
+            SEXP reb = allocMatrix(REALSXP, B + 1, S); SET_VECTOR_ELT(out, 15, reb);
+            for (int s = 0; s < S; s++) {
+              for (int g = 0; g < B; g++) REAL(rpb)[(size_t)s * B + g] = pb[(size_t)g * S + s];
+              for (int g = 0; g <= B; g++) REAL(reb)[(size_t)s * (B + 1) + g] = eb[(size_t)g * S + s];
+              REAL(rphi)[s] = NA_REAL;
+            }
+          }
+        }
+        set_names(out, names, 16);
       }
     }
   }
@@ -286,7 +311,7 @@ static const R_CallMethodDef CallEntries[] = {                                /*
   {"C_hmm",              (DL_FUNC) &C_hmm,              6},
   {"get_loglike_matrix", (DL_FUNC) &get_loglike_matrix, 5},
   /* cohort-level entries of this library (not in the reference) */
-  {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      13},
+  {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      14},
   {"ed_fit_betabin_batch",    (DL_FUNC) &edr_fit_betabin_batch,    3},
   {"ed_select_reference_set", (DL_FUNC) &edr_select_reference_set, 4},
   {"ed_cohort_reference_sets", (DL_FUNC) &edr_cohort_reference_sets, 4},

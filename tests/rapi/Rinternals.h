@@ -25,10 +25,12 @@ typedef enum { FALSE = 0, TRUE } Rboolean;
 #define VECSXP 19
 #define RAWSXP 24
 #define NA_INTEGER R_NaInt
+#define NA_REAL R_NaReal
 
 extern SEXP R_NilValue;
 extern SEXP R_NamesSymbol;
 extern int R_NaInt;
+extern double R_NaReal;
 typedef unsigned char Rbyte;
 
 double *REAL(SEXP x);

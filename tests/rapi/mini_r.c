@@ -17,6 +17,13 @@ static struct SEXPREC names_sym = {1, 0, 0, 0, NULL, NULL};
 SEXP R_NilValue = &nil_rec;
 SEXP R_NamesSymbol = &names_sym;
 int R_NaInt = (-2147483647 - 1);
+double R_NaReal;   /* R's NA_real_ is the NaN with payload 1954 (arithmetic.c): set when the library is loaded */
+static void __attribute__((constructor)) minir_set_na(void)
+{
+  union { double d; unsigned long long u; } v;
+  v.u = 0x7FF00000000007A2ULL;
+  R_NaReal = v.d;
+}
 
 static char g_out[1 << 20];
 static size_t g_out_len = 0;
@@ -145,6 +152,8 @@ SEXP minir_callv(void *fn, int nargs, SEXP *a)
       case 6: r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP))fn)(a[0], a[1], a[2], a[3], a[4], a[5]); break;
       case 13: r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP))fn)(
                    a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]); break;
+      case 14: r = ((SEXP (*)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP))fn)(
+                   a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]); break;
       default: snprintf(g_err, sizeof g_err, "mini_r: no caller for %d arguments", nargs);
     }
   }

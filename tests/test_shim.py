@@ -125,7 +125,7 @@ def test_registration_is_the_references(shim):
     next to them the three cohort-level entries of this library."""
     names = [shim.R.minir_registered_name(i).decode() for i in range(shim.R.minir_n_registered())]
     assert names[:2] == ["C_hmm", "get_loglike_matrix"]
-    assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5, "ed_call_cnvs_batch": 13,
+    assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5, "ed_call_cnvs_batch": 14,
                                                           "ed_fit_betabin_batch": 3, "ed_select_reference_set": 4, "ed_cohort_reference_sets": 4}
     assert shim.R.minir_dynamic_symbols() == 0
     for name in ("C_hmm", "get_loglike_matrix"):
@@ -253,11 +253,13 @@ def test_call_cnvs_batch_through_sexp_equals_ctypes_path(shim, edlib, given, sla
     E, S = test.shape
     res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
                                   shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.real(phi) if given else shim.nil,
-                                  shim.real(p) if given else shim.nil, shim.real([1.0]), shim.integer([slab]), shim.integer([1]), shim.integer([mode]))
+                                  shim.real(p) if given else shim.nil, shim.real([1.0]), shim.integer([slab]), shim.integer([1]), shim.integer([mode]),
+                                  shim.integer([1]))
     assert res is not None and err == "" and out == ""
     got = shim.as_list(res)
     assert list(got) == ["sample", "start.p", "end.p", "type", "nexons", "BF", "reads.expected", "reads.observed", "reads.ratio", "phi",
-                         "expected", "path", "n.unconverged", "n.gsl.errors"]
+                         "expected", "path", "n.unconverged", "n.gsl.errors", "phi.bins", "complete.bins"]
+    assert got["phi.bins"] is None and got["complete.bins"] is None
     plan = edlib.Plan(chrom_off, start, end)
     b = edlib.Batch(plan, S)
     if mode:
@@ -292,6 +294,41 @@ def test_call_cnvs_batch_through_sexp_equals_ctypes_path(shim, edlib, given, sla
     assert got["n.unconverged"][0] == 0 and got["n.gsl.errors"][0] == 0
     assert shim.R.minir_protect_balance() == 0
     b.close(); plan.close()
+
+
+@pytest.mark.gpu
+def test_call_cnvs_batch_with_phi_bins_through_sexp(shim, edlib):
+    """the reference's phi.bins argument (R/class_definition.R:86, :120-147) through .Call("ed_call_cnvs_batch", ..., phi.bins = 3):
+    phi.estimates per depth level and complete.bins come back as matrices, `phi` is NA, and calls / decoration / path are those of
+    ed_batch_run_bins given these parameters, bit for bit"""
+    chrom_off, start, end, test, ref, p, phi = _cohort_case()
+    E, S = test.shape
+    B = 3
+    res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
+                                  shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.nil, shim.nil, shim.real([1.0]),
+                                  shim.integer([150]), shim.integer([1]), shim.integer([0]), shim.integer([B]))
+    assert res is not None and err == "" and out == ""
+    got = shim.as_list(res)
+    phib = np.asarray(got["phi.bins"]).reshape(S, B).T            # B x S, column-major
+    edges = np.asarray(got["complete.bins"]).reshape(S, B + 1).T
+    assert np.all(np.isnan(got["phi"])) and np.all(phib > 0) and np.all(np.diff(edges, axis=0) >= 0)
+    plan = edlib.Plan(chrom_off, start, end)
+    b = edlib.Batch(plan, S)
+    d = [edlib.DeviceArray(np.zeros((B, S))), edlib.DeviceArray(np.zeros((B + 1, S))), edlib.DeviceArray(np.zeros(S))]
+    b.fit_bins(test, ref, B, *d)
+    assert np.array_equal(edges, d[1].to_host()) and np.max(np.abs(phib - d[0].to_host()) / phib) < 1e-9
+    b.run_bins(test, ref, B, np.ascontiguousarray(phib), np.ascontiguousarray(edges), got["expected"])
+    calls, info = b.calls(), b.call_info()
+    assert np.array_equal(got["sample"], calls["sample"] + 1) and np.array_equal(got["start.p"], calls["start_exon"] + 1)
+    assert np.array_equal(got["end.p"], calls["end_exon"] + 1) and np.array_equal(got["type"], calls["type"]) and len(calls) > 50
+    assert got["BF"].tobytes() == info["BF"].tobytes() and np.array_equal(got["path"], b.path())
+    b.close(); plan.close()
+    # parameters cannot be given in this mode: an R error before any device work
+    res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
+                                  shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.real(phi), shim.real(p), shim.real([1.0]),
+                                  shim.integer([150]), shim.integer([0]), shim.integer([0]), shim.integer([B]))
+    assert res is None and "phi.bins" in err
+    assert shim.R.minir_protect_balance() == 0
 
 
 @pytest.mark.gpu
