@@ -1335,6 +1335,26 @@ k_fit_start(const double* __restrict__ partial, int64_t nchunk, int64_t S, doubl
   if (cnt > 0) atomicMax(depth_max, (int)fmin(sn / cnt, 2.0e9));
 }
 
+// select.reference.set for a cohort (edrefcohort.inc): column i * T + j is test j against its i + 1 best candidates summed, and the
+// reference's loop stops at the first i + 1 > 2 whose fitted proportion is below 0.05 (R/optimize_reference_set.R:130) -- the
+// prefixes after that are never looked at.  The proportion falls as references are added, and its moment estimate (sum y / sum n,
+// the start value in eta) is within a few per cent of the fitted one: the columns after the first prefix whose moment estimate is
+// below `p_limit` (0.04: 20 % of margin) are marked done before the Newton passes.  skip_from[j] = the first prefix skipped (K if
+// none): the caller falls back to the slow path should the fitted loop ever reach it.
+__global__ void k_fit_skip_prefixes(const double* __restrict__ eta, int* __restrict__ done, int K, int64_t T, double p_limit,
+                                    int* __restrict__ skip_from)
+{
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= T) return;
+  int from = K;
+  for (int i = 0; i < K; ++i) {
+    if (i >= from) { done[(int64_t)i * T + j] = 1; continue; }
+    const double p = 1.0 / (1.0 + ed_pexp(-eta[(int64_t)i * T + j]));
+    if (i + 1 > 2 && p < p_limit) from = i + 1;
+  }
+  skip_from[j] = from;
+}
+
 __global__ void __launch_bounds__(kWave * kFitSub)
 k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t rrs,
             int64_t E, int64_t S, int stride, const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
@@ -2579,7 +2599,7 @@ static void fitwork_free(FitWork* w)
 // out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
                        int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0, int fit_mode = 0,
-                       int64_t tmod = 0)
+                       int64_t tmod = 0, int skip_K = 0, int* d_skip_from = nullptr)
 {
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
   const int64_t nch = nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
@@ -2630,6 +2650,8 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     HIP_TRY(hipGetLastError());
     return ED_OK;
   }
+  if (skip_K > 0 && tmod > 0 && d_skip_from)
+    hipLaunchKernelGGL(k_fit_skip_prefixes, dim3((unsigned)((tmod + 255) / 256)), dim3(256), 0, st, w.eta, w.done, skip_K, tmod, 0.04, d_skip_from);
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
   const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   for (int it = 0; it < coarse; ++it) {
