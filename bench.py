@@ -234,8 +234,30 @@ def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
         co.close()
         if kind == "pinned":
             pt.free(); pr.free()
+    # the reference's workflow: a sample's reference is the sum of other samples of the cohort, made ON THE DEVICE by
+    # ed_cohort_select_reference_sets -- only the test counts cross the link (ed_cohort_submit_host_test)
+    pt = ed.PinnedArray((E, S), dt)
+    pt.array[...] = th
+    co = ed.Cohort(plan, S, max(3, n_batches))      # (three slabs in flight: the upload of slab t+2 starts while slab t's chains still run)
+    sub = (lambda: co.submit_host_test(pt.array, ref, 0)) if args.fit else (lambda: co.submit_host_test(pt.array, ref, 0, phi=phi, expected=p))
+    for _ in range(max(3, n_batches) + 1):
+        sub()
+    co.drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sub()
+    co.drain()
+    el = time.perf_counter() - t0
+    out["test_only"] = {"ms_per_step": el / args.steps * 1e3, "value": E * S * args.steps / el, "link_GBps": 1.0 * E * S * args.wire * args.steps / el / 1e9}
+    co.close()
+    pt.free()
     return {"value_with_h2d": out["pinned"]["value"], "unit": "exons*samples/s", "wire_bytes_per_count": args.wire,
             "bytes_per_step": 2.0 * E * S * args.wire, "pinned": out["pinned"], "pageable": out["pageable"],
+            "test_counts_only": out["test_only"],
+            "test_counts_only_note": "the references stay on the device (in the reference's workflow they are sums of other samples of the same cohort: "
+                                     "ed_cohort_select_reference_sets): one matrix per slab on the link",
+
             "pcie_peak_GBps": 63.0,
             "note": "every step uploads both count matrices of its slab from host memory (PCIe Gen5 x16: 63 GB/s peak) on the cohort's copy "
                     "stream while earlier slabs compute; link_GBps = bytes on the link / wall time of the steps"}

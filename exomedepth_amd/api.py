@@ -556,6 +556,27 @@ class Cohort:
         self._keep[t.value % self.slabs_in_flight] = keep + [test, ref]
         return t.value
 
+    def submit_host_test(self, test, ref, layout, phi=None, expected=None, mixture=1.0, n_samples=None, row_stride=None):
+        """one slab whose TEST counts come from host memory (as submit_host) and whose references are on the device already
+        (ref: (n_exons, n) int32 CUDA tensor / DeviceArray -- e.g. a window of cohort_select_reference_sets' aggregate references)"""
+        test = np.asarray(test)
+        if test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
+            raise ValueError("test must be int32 or uint16")
+        wire = test.dtype.itemsize
+        if n_samples is None:
+            n_samples = int(test.shape[1] if layout == 0 else test.shape[0])
+        if row_stride is None:
+            row_stride = int(test.strides[0] // wire) if layout == 0 else 0
+        keep = []
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi, np.float64, keep) if phi is not None else None
+        pe = _device_pointer(expected, np.float64, keep) if expected is not None else None
+        t = C.c_int64(-1)
+        check(lib().ed_cohort_submit_host_test(self.handle, C.c_void_p(test.ctypes.data), pr, int(n_samples), int(layout), int(wire),
+                                               int(row_stride), pp, pe, float(mixture), C.byref(t)))
+        self._keep[t.value % self.slabs_in_flight] = keep + [test, ref]
+        return t.value
+
     def batch(self, ticket):
         """(Batch view, device pointer of phi, device pointer of expected) of a ticket"""
         h, pp, pe = C.c_void_p(), C.c_void_p(), C.c_void_p()

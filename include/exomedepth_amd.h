@@ -426,6 +426,12 @@ void* ed_cohort_stream(ed_cohort* cohort);               /* the pipeline's main 
 int ed_cohort_stage_ms_total(ed_cohort* cohort, double ms_total[5], int64_t* n_runs, int64_t* n_fits);
 int ed_cohort_n_emit_launches(ed_cohort* cohort);
 
+/* ed_cohort_submit_host with only the TEST counts in host memory and the references on the device (d_ref: int32
+ * [n_exons][n_samples] sample-minor, complete when this is called).  In the reference's workflow a sample's reference is the sum of
+ * other samples of the same cohort (vignette/vignette.Rnw:390-402): ed_cohort_select_reference_sets makes it on the device from counts
+ * uploaded once, so only one matrix per slab crosses the link. */
+int ed_cohort_submit_host_test(ed_cohort* cohort, const void* test, const int32_t* d_ref, int64_t n_samples, int layout, int wire,
+                               int64_t row_stride, const double* phi, const double* expected, double mixture, int64_t* ticket);
 /* ---- slabs from host memory (ingest) ----
  * layout 0: the host matrix is [n_exons][row_stride] sample-minor (the EDCOUNT1 container of exomedepth_amd/io.py); the slab
  *           is its first n_samples columns from the given pointer (row_stride = the cohort's width for a window of columns)

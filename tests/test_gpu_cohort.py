@@ -273,3 +273,21 @@ def test_an_empty_depth_level_is_the_error_of_its_ticket(cohort_data):
         co.wait(t1)
     _bins_check(edlib, plan, slabs[3], B, co.results(t2, S, path=True, loglik=True), ref_res[1])
     co.close()
+
+
+def test_test_counts_from_the_host_references_on_the_device(cohort_data):
+    """ed_cohort_submit_host_test: only the test matrix crosses the link (16-bit wire format, R's layout), the references are device-resident"""
+    edlib, plan, slabs, want, S = cohort_data
+    co = edlib.Cohort(plan, S, 2)
+    tickets = []
+    keep = []
+    for i, (t, r) in enumerate(slabs):
+        dr = edlib.DeviceArray(r); keep.append(dr)
+        if i % 2 == 0:
+            tickets.append(co.submit_host_test(np.ascontiguousarray(t.T.astype(np.uint16)), dr, 1))
+        else:
+            tickets.append(co.submit_host_test(t.astype(np.int32), dr, 0))
+        if i >= 1:
+            _same(co.results(tickets[i - 1], slabs[i - 1][0].shape[1], path=True), want[i - 1], ("calls", "info", "path", "phi", "expected"))
+    _same(co.results(tickets[-1], slabs[-1][0].shape[1], path=True), want[-1], ("calls", "info", "path", "phi", "expected"))
+    co.close()
