@@ -263,6 +263,48 @@ def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
                     "stream while earlier slabs compute; link_GBps = bytes on the link / wall time of the steps"}
 
 
+def workflow_leg(ed, torch, plan, test, start, end, E, S, reps):
+    """The reference's workflow for one cohort (vignette/vignette.Rnw:390-431), end to end from host memory: upload the cohort's counts
+    once (16-bit, pinned), select.reference.set for every sample against all the others + the aggregate references on the device
+    (ed_cohort_select_reference_sets, n.bins.reduced = 10 000 as in the vignette), then new('ExomeDepth') + CallCNVs() for every sample
+    through the cohort pipeline with the device-resident matrices.  The synthetic 'test' matrix stands for the cohort's counts."""
+    th = test.cpu().numpy()
+    if th.max() >= 65536:
+        return None
+    pin = ed.PinnedArray((E, S), np.uint16)
+    pin.array[...] = th
+    bl = (np.asarray(end) - np.asarray(start)) / 1000.0
+    stream = torch.cuda.current_stream()
+    times = {"upload_ms": [], "reference_sets_ms": [], "calls_ms": [], "total_ms": []}
+    n_calls = n_chosen = None
+    co = ed.Cohort(plan, S, 1)
+    for rep in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dcounts = torch.from_numpy(pin.array.view(np.int16)).to(test.device, non_blocking=True).view(torch.int16).to(torch.int32) & 0xffff
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        tk = co.submit(dcounts, rs["reference"], n_samples=S)
+        co.wait(tk)
+        b, _, _ = co.batch(tk)
+        n_calls = b.n_calls()
+        t3 = time.perf_counter()
+        n_chosen = float(rs["n_chosen"].mean())
+        if rep > 0:                                   # (the first repetition allocates)
+            for k, v in zip(("upload_ms", "reference_sets_ms", "calls_ms", "total_ms"), (t1 - t0, t2 - t1, t3 - t2, t3 - t0)):
+                times[k].append(v * 1e3)
+        del rs
+    co.close(); pin.free()
+    med = {k: float(np.median(v)) for k, v in times.items()}
+    return {"workload": "one cohort of %d samples x %d exons: counts from pinned host memory (uint16) -> reference sets of every sample against all "
+                        "others (n.bins.reduced 10000, <= 32 candidates) + aggregate references on the device -> fit + emissions + Viterbi + calls; "
+                        "stages one after the other (one cohort, nothing to overlap with), median of %d" % (S, E, reps),
+            **med, "value": E * S / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls}
+
+
 def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps):
     """BASELINE configs[1]: 200 000 exons x 64 samples, phi given (no fit) -- the first 64 columns of the batch through the cohort
     pipeline (two slabs in flight), and one slab at a time (the latency of a lone slab: bound by the longest chromosome's chain)."""
@@ -334,6 +376,8 @@ def main():
                     "the headline and reported under extra.config1 (0 = skip)")
     ap.add_argument("--verify-columns", type=int, default=4, help="columns of the last slabs checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
+    ap.add_argument("--workflow-reps", type=int, default=3, help="after the timed region (N = 1): the reference's workflow for one cohort end to end -- "
+                    "upload, reference sets, calls -- reported under extra.workflow; 0: skip")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
@@ -615,6 +659,9 @@ def main():
     staged = None
     if world == 1 and args.stage_inputs and use_cohort:
         staged = staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
+    workflow = None
+    if world == 1 and args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64:
+        workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps)
 
     if rank == 0:
         kernel = "k_emit_viterbi" if args.fused else ("k_emit_batch" if plain else "k_emit_bins")
@@ -666,7 +713,7 @@ def main():
             "n_calls": n_calls,
             "verify": verify,
             "fit_concordance": fit_conc,
-            "extra": {"config1": config1},
+            "extra": {"config1": config1, "workflow": workflow},
         }
         if staged:
             out["value_with_h2d"] = staged.pop("value_with_h2d")

@@ -2,7 +2,7 @@
 # Diagnostic PMC passes on the emission kernel: instruction cache, issue mix, LDS.   tools/pmc_diag.sh <tag>
 set -u
 TAG=${1:-pmcd}; OUT=gpurun_out/$TAG; export TMPDIR=/tmp; mkdir -p $OUT
-B="python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0"
+B="python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0"
 i=0
 for C in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" \
          "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_BUSY_CYCLES" \

@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT -o pq -- \
-  python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 > $OUT/pq.log 2>&1
+  python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 > $OUT/pq.log 2>&1
 python tools/pmc_summary.py $OUT/pq_counter_collection.csv > $OUT/pmc_quick.csv
 rm -f $OUT/pq_counter_collection.csv $OUT/pq_kernel_trace.csv $OUT/*agent_info.csv
 python - "$OUT" <<'PY'

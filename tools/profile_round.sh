@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python bench.py --steps 5 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 > $OUT/bench_ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python bench.py --steps 5 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 > $OUT/bench_ks.log 2>&1
 grep -h '^{' $OUT/bench_ks.log > $OUT/bench_line.json
 python - "$OUT" <<'PY'
 import csv, sys
@@ -22,7 +22,7 @@ PY
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   N=$(echo $C | cut -d' ' -f1)
   [ "$N" = "SQ_WAVES" ] && N=SQ
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o pmc_$N -- python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 > $OUT/pmc_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o pmc_$N -- python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 > $OUT/pmc_$N.log 2>&1
   python tools/pmc_summary.py $OUT/pmc_${N}_counter_collection.csv > $OUT/pmc_$N.csv
   rm -f $OUT/pmc_${N}_counter_collection.csv $OUT/pmc_${N}_kernel_trace.csv
 done
