@@ -30,6 +30,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 

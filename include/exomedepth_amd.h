@@ -349,6 +349,9 @@ int ed_cohort_select_reference_sets(const int32_t* d_counts, int64_t n_bins, int
                                     int64_t n_bins_reduced, int32_t max_refs, int32_t* n_chosen, int32_t* choice, ed_refset_row* rows,
                                     double* correlations, int32_t* d_ref_out, int64_t* n_selected_bins, void* stream);
 
+/* ed_cohort_select_reference_sets keeps its device scratch (about 1.5 GB at 10 000 selected bins x 1024 samples) between calls;
+ * this returns it to the device. */
+int ed_release_scratch(void);
 /* ... on host data in R's layout: counts the n_bins x n_samples integer matrix, column-major; reference_out_colmajor (optional)
  * receives the aggregate reference in the same layout.  The other arguments as above. */
 int ed_cohort_select_reference_sets_host(const int32_t* counts_colmajor, int64_t n_bins, int64_t n_samples, const double* bin_length,
