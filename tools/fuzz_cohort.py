@@ -2,7 +2,9 @@
   * the cohort pipeline (ed_cohort_run_host: random slab sizes, slabs in flight, layouts, wire formats, options) against the batch
     interface on the same data, bit for bit;
   * fit mode 1 (aod-nm on the device) against the checker's nmmin, within the search's tolerance;
-  * ed_cohort_select_reference_sets against one ed_select_reference_set call per sample: identical choices.
+  * ed_cohort_select_reference_sets against one ed_select_reference_set call per sample: identical choices;
+  * the depth-binned model through the pipeline (option phi_bins: fit issued blind, settled at the first wait; declined slabs done
+    again per cell; an empty level = the run's error) against ed_batch_fit_bins + ed_batch_run_bins.
     python tools/fuzz_cohort.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,9 +19,9 @@ from oracle import edoracle as eo
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 t0 = time.time()
-n = {"cohort": 0, "nm": 0, "refcohort": 0, "refcohort_fallback": 0}
+n = {"cohort": 0, "nm": 0, "refcohort": 0, "refcohort_fallback": 0, "cohort_bins": 0, "cohort_bins_rejected": 0}
 while time.time() - t0 < budget:
-    kind = rng.choice(["cohort", "cohort", "nm", "refcohort"])
+    kind = rng.choice(["cohort", "cohort", "nm", "refcohort", "cohort_bins"])
     seed = int(rng.integers(1 << 30))
     if kind == "cohort":
         S = int(rng.choice([1, 2, 5, 63, 64, 65, 130, 257]))
@@ -60,6 +62,41 @@ while time.time() - t0 < budget:
             np.savez("gpurun_out/fuzz_cohort_case.npz", test=test, ref=ref, chrom_off=chrom_off, start=start, end=end, slab=slab, nf=nf, layout=layout, wire=wire)
             raise SystemExit("cohort mismatch: seed %d S %d E %d slab %d in flight %d layout %d wire %d given %s" % (seed, S, E, slab, nf, layout, wire, given))
         co.close(); plan.close()
+    elif kind == "cohort_bins":
+        S = int(rng.choice([3, 5, 17, 64, 70])); C = int(rng.integers(1, 4)); E = int(rng.integers(600, 9000)); B = int(rng.integers(2, 9))
+        chrom_off, start, end = synth.exon_design(E, C, seed)
+        depth = float(rng.choice([30.0, 90.0, 250.0, 900.0]))          # (900: reference counts beyond the histogram form's bins)
+        test, ref, _, _, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=2, mean_depth=depth)
+        plan = ed.Plan(chrom_off, start, end)
+        slab = int(rng.integers(2, S + 1)); nf = int(rng.integers(1, 4)); layout = int(rng.integers(0, 2))
+        th = test if layout == 0 else np.ascontiguousarray(test.T)
+        rh = ref if layout == 0 else np.ascontiguousarray(ref.T)
+        co = ed.Cohort(plan, slab, nf, phi_bins=B)
+        try:
+            out = co.run_host(th, rh, layout, want_path=True)
+        except ed.EdError as e:
+            assert "Binning did not happen properly" in str(e), str(e)
+            b = ed.Batch(plan, S)
+            d = [ed.DeviceArray(np.zeros((B, S))), ed.DeviceArray(np.zeros((B + 1, S))), ed.DeviceArray(np.zeros(S))]
+            try:
+                b.fit_bins(test, ref, B, *d)
+                raise SystemExit("cohort_bins: the pipeline rejects, the batch interface does not: seed %d" % seed)
+            except ed.EdError:
+                pass
+            b.close(); co.close(); plan.close()
+            n["cohort_bins_rejected"] += 1
+            continue
+        path = out["path"] if layout == 0 else out["path"].T
+        b = ed.Batch(plan, S)
+        d = [ed.DeviceArray(np.zeros((B, S))), ed.DeviceArray(np.zeros((B + 1, S))), ed.DeviceArray(np.zeros(S))]
+        b.fit_bins(test, ref, B, *d)
+        pb, eb, xb = [x.to_host() for x in d]
+        if not (np.array_equal(out["edges"], eb) and np.allclose(out["phi_bins"], pb, rtol=1e-7, atol=0) and np.allclose(out["expected"], xb, rtol=1e-8, atol=0)):
+            raise SystemExit("cohort_bins fit mismatch: seed %d S %d E %d B %d slab %d in flight %d depth %g" % (seed, S, E, B, slab, nf, depth))
+        b.run_bins(test, ref, B, out["phi_bins"], out["edges"], out["expected"])
+        if not (out["calls"].tobytes() == b.calls().tobytes() and out["info"].tobytes() == b.call_info().tobytes() and np.array_equal(path, b.path())):
+            raise SystemExit("cohort_bins mismatch: seed %d S %d E %d B %d slab %d in flight %d layout %d depth %g" % (seed, S, E, B, slab, nf, layout, depth))
+        b.close(); co.close(); plan.close()
     elif kind == "nm":
         S = int(rng.choice([1, 4, 9])); E = int(rng.integers(300, 20000))
         chrom_off, start, end = synth.exon_design(E, 1, seed)
