@@ -278,16 +278,17 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps):
     times = {"upload_ms": [], "reference_sets_ms": [], "calls_ms": [], "total_ms": []}
     n_calls = n_chosen = None
     co = ed.Cohort(plan, S, 1)
+    ref_t = torch.empty((E, S), dtype=torch.int32, device=test.device)
     for rep in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         dcounts = torch.from_numpy(pin.array.view(np.int16)).to(test.device, non_blocking=True).view(torch.int16).to(torch.int32) & 0xffff
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32)
+        rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32, reference_out=ref_t)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        tk = co.submit(dcounts, rs["reference"], n_samples=S)
+        tk = co.submit(dcounts, ref_t, n_samples=S)     # (two half-cohort slabs through the pipeline were tried: 17 ms against 12.7 -- the slicing copies cost more than the overlap gives)
         co.wait(tk)
         b, _, _ = co.batch(tk)
         n_calls = b.n_calls()

@@ -887,7 +887,8 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
     return {"reference.choice": choice, "summary.stats": rows, "n.bins": int(n_sel.value)}
 
 
-def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_refs=32, want_reference=True, want_correlations=False):
+def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_refs=32, want_reference=True, want_correlations=False,
+                                 reference_out=None):
     """select.reference.set for every sample of a cohort against all the others (reference vignette/vignette.Rnw:390-402 loop;
     R/optimize_reference_set.R:53-148 per sample), in one call.
 
@@ -904,16 +905,21 @@ def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_
     choice = np.full((S, K), -1, dtype=np.int32)
     rows = np.zeros((S, K), dtype=REFSET_DTYPE)
     corr = np.zeros((S, S)) if want_correlations else None
-    ref = DeviceArray(nbytes=E * S * 4) if want_reference else None
+    ref = DeviceArray(nbytes=E * S * 4) if (want_reference and reference_out is None) else None
     if ref is not None:
         ref.host_dtype, ref.shape = np.dtype(np.int32), (E, S)
+    ref_ptr = ref.ptr if ref is not None else None
+    if reference_out is not None:          # the caller's own (E, S) int32 device array (a torch CUDA tensor, say) receives the aggregate references
+        ref_ptr = _device_pointer(reference_out, np.int32, keep)
     nsel = C.c_int64(0)
     check(lib().ed_cohort_select_reference_sets(pc, E, S, _ptr(bl) if bl is not None else None, int(n_bins_reduced), K, _ptr(n_chosen),
                                                 _ptr(choice), _ptr(rows), _ptr(corr) if corr is not None else None,
-                                                ref.ptr if ref is not None else None, C.byref(nsel), None))
+                                                ref_ptr, C.byref(nsel), None))
     out = {"n_chosen": n_chosen, "choice": choice, "summary.stats": rows, "n.bins": int(nsel.value)}
     if ref is not None:
         out["reference"] = ref
+    elif reference_out is not None:
+        out["reference"] = reference_out
     if corr is not None:
         out["correlations"] = corr
     return out
