@@ -156,7 +156,7 @@ def _device_view(torch, eddist, ptr, shape, typestr, dev):
 
 
 def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_batches, test, ref, phi, p, phi_fit, p_fit, fitted,
-                          chrom_off, start, end, k):
+                          chrom_off, start, end, k, tables=False):
     """k columns of each of the last slabs in flight against the CPU checker (oracle/, the checker -- never the thing timed):
     the bits of the likelihood matrix vs its portable flavour, Viterbi states and call rows vs its Viterbi run on its own matrix,
     given the (phi, expected) the device used for that slab."""
@@ -165,6 +165,9 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
     E, S = test.shape
     cols = sorted(set(int(c) for c in np.linspace(0, S - 1, k).round()))
     out = {"columns": 0, "loglik_values": 0, "loglik_bit_mismatches": 0, "discordant_states": 0, "discordant_calls": 0, "slabs": 0}
+    if tables:   # emit mode 1: tolerance parity against the LIBM flavour (= the reference's arithmetic), 1e-10 relative / 1e-12 absolute
+        out = {"columns": 0, "loglik_values": 0, "loglik_beyond_1e-10": 0, "loglik_max_rel_diff": 0.0, "discordant_states": 0,
+               "discordant_calls": 0, "slabs": 0}
     slabs = []
     if co is not None:
         for t in range(max(0, last_ticket - n_batches + 1), last_ticket + 1):
@@ -185,10 +188,17 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
         path = _device_view(torch, eddist, ptr["path"], (E, S), "|u1", dev)[:, cols].cpu().numpy()
         out["slabs"] += 1
         for i, c in enumerate(cols):
-            ell, _ = eo.get_loglike_matrix(ph[c], pe[c], th[:, i] + rh[:, i], th[:, i], 1.0, eo.PORTABLE)
+            ell, _ = eo.get_loglike_matrix(ph[c], pe[c], th[:, i] + rh[:, i], th[:, i], 1.0, eo.LIBM if tables else eo.PORTABLE)
             got = np.ascontiguousarray(ll[:, :, i])
             out["loglik_values"] += int(got.size)
-            out["loglik_bit_mismatches"] += int(np.sum(got.view(np.int64) != np.ascontiguousarray(ell).view(np.int64)))
+            if tables:
+                d = np.abs(got - ell)
+                out["loglik_beyond_1e-10"] += int(np.sum(~((d <= np.maximum(1e-12, 1e-10 * np.abs(ell))) | (np.isnan(got) & np.isnan(ell)))))
+                nz = np.isfinite(ell) & (ell != 0)
+                if nz.any():
+                    out["loglik_max_rel_diff"] = max(out["loglik_max_rel_diff"], float(np.max(d[nz] / np.abs(ell[nz]))))
+            else:
+                out["loglik_bit_mismatches"] += int(np.sum(got.view(np.int64) != np.ascontiguousarray(ell).view(np.int64)))
             epath, ecalls = eo.callcnvs(ell, chrom_off, start, end)
             out["discordant_states"] += int(np.sum(path[:, i].astype(np.int8) != epath))
             mine = calls[calls["sample"] == c]
@@ -196,8 +206,10 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
             have = {(int(r["start_exon"]), int(r["end_exon"]), int(r["type"]), int(r["nexons"])) for r in mine}
             out["discordant_calls"] += len(want ^ have)
             out["columns"] += 1
-    out["what"] = ("%d columns x %d slab(s) in flight after the timed region: likelihood bits vs the checker's portable flavour, Viterbi "
-                   "states and call rows vs the checker's Viterbi, given the (phi, expected) the device used" % (len(cols), len(slabs)))
+    out["what"] = ("%d columns x %d slab(s) in flight after the timed region: %s, Viterbi "
+                   "states and call rows vs the checker's Viterbi, given the (phi, expected) the device used"
+                   % (len(cols), len(slabs), "likelihood values vs the checker's LIBM flavour (the reference's arithmetic), 1e-10 relative / 1e-12 absolute"
+                      if tables else "likelihood bits vs the checker's portable flavour"))
     return out
 
 
@@ -343,6 +355,9 @@ def main():
     ap.add_argument("--chroms", type=int, default=24)
     ap.add_argument("--depth", type=float, default=100.0, help="median reads per exon and sample of the synthetic counts (SURVEY.md 8d: 100)")
     ap.add_argument("--fit", type=int, default=1, help="1 (default): the step includes the per-sample dispersion fit (configs[2]); 0: phi given (configs[1] style)")
+    ap.add_argument("--emit-mode", default="strict", choices=["strict", "tables"], help="strict: every log-Beta through GSL's routes operation for "
+                    "operation (bit-identical to the checker); tables: per-(sample, state) log-gamma difference tables, three gathers and a sum "
+                    "per cell (csrc/edtab.inc; within 1e-10 of the reference's arithmetic, verified after the timed region)")
     ap.add_argument("--fused", type=int, default=0, help="1: emissions + Viterbi as one kernel (csrc/edfused.inc)")
     ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
     ap.add_argument("--phi-bins", type=int, default=1, help="> 1: the depth-binned dispersion model (phi.bins, csrc/edbins.inc); "
@@ -480,6 +495,8 @@ def main():
             opts["own_queues"] = args.own_queues
         if args.tables_early >= 0:
             opts["tables_early"] = args.tables_early
+        if args.emit_mode == "tables" and not bins_cohort:
+            opts["emit_mode"] = 1
         if bins_cohort:
             opts["phi_bins"] = args.phi_bins          # the depth-binned model through the same pipeline (option phi_bins)
             if os.environ.get("ED_BENCH_BINS_PIECES"):
@@ -519,6 +536,8 @@ def main():
             b.set_fused(bool(args.fused))
             b.keep_loglik(bool(args.keep_loglik))
             b.set_async_tail(n_batches >= 2)
+            if args.emit_mode == "tables" and plain and not args.fused:
+                b.set_emit_mode(1)
             if n_batches >= 2 and args.viterbi_overlap >= 0:
                 b.set_viterbi_overlap(bool(args.viterbi_overlap))
         main_stream = torch.cuda.current_stream()
@@ -650,7 +669,7 @@ def main():
     if world == 1 and args.verify_columns > 0 and plain and not args.fused:      # (N = 1 only, like cpu_baseline: the other ranks would wait)
         verify = verify_against_oracle(ed, eddist, torch, dev, co if use_cohort else None, batches, last_ticket[0] if use_cohort else None,
                                        n_batches, test, ref, phi, p, phi_fit if not use_cohort else None, p_fit if not use_cohort else None,
-                                       bool(args.fit), chrom_off, start, end, args.verify_columns)
+                                       bool(args.fit), chrom_off, start, end, args.verify_columns, tables=args.emit_mode == "tables")
     fit_conc = None
     if world == 1 and args.fit and plain and not args.fused and args.fit_concordance > 0:
         from exomedepth_amd import concordance
@@ -667,7 +686,7 @@ def main():
         workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps)
 
     if rank == 0:
-        kernel = "k_emit_viterbi" if args.fused else ("k_emit_batch" if plain else "k_emit_bins")
+        kernel = "k_emit_viterbi" if args.fused else (("k_emit_tab" if args.emit_mode == "tables" else "k_emit_batch") if plain else "k_emit_bins")
         t_emit = stage_ms["emissions"] * 1e-3
         achieved = ALGO_BYTES_PER_CELL * E * S / t_emit / 1e9 if t_emit > 0 else 0.0
         kernel_cells_per_s = (E * S / t_emit) if t_emit else 0.0
@@ -689,7 +708,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
-                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "emit_mode": args.emit_mode, "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
                        "batches_in_flight": n_batches, "driver": ("cohort (ed_cohort_submit: the library's own streams and batch rotation)" if use_cohort else "python (torch streams)"),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered to rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,

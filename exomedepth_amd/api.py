@@ -431,6 +431,44 @@ class Batch:
                for i in range(min(int(cap), nbad.value))]
         return ncmp.value, nbad.value, rec
 
+    def set_emit_mode(self, mode, cap_obs=None, cap_ref=None, reach=None):
+        """mode 0 / "strict": GSL's arithmetic operation for operation (default); 1 / "tables": log-gamma difference tables per
+        (sample, state) -- three gathers and a sum per cell, ~1e-14 relative (see ed_batch_set_emit_mode)."""
+        m = {"strict": 0, "tables": 1}.get(mode, mode)
+        if cap_obs is not None or cap_ref is not None or reach is not None:
+            check(lib().ed_batch_set_emit_tables(self.handle, int(cap_obs or 4096), int(cap_ref or 32768), float(reach or 8.0)))
+        check(lib().ed_batch_set_emit_mode(self.handle, int(m)))
+
+    def verify_emissions_tol(self, test, ref, phi, expected, mixture=1.0, rel_tol=1e-10, abs_tol=1e-12, cap=16):
+        """verify_emissions with a tolerance: returns a dict(compared, beyond, max_rel, max_abs, first)."""
+        keep = []
+        pt = _device_pointer(test, np.int32, keep)
+        pr = _device_pointer(ref, np.int32, keep)
+        pp = _device_pointer(phi, np.float64, keep)
+        pe = _device_pointer(expected, np.float64, keep)
+        first = (_lib.EdEmitMismatch * max(int(cap), 1))()
+        ncmp, nbad, mr, ma = C.c_int64(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        check(lib().ed_batch_verify_emissions_tol(self.handle, pt, pr, pp, pe, float(mixture), float(rel_tol), float(abs_tol), C.byref(ncmp),
+                                                  C.byref(nbad), C.byref(mr), C.byref(ma), C.cast(first, C.c_void_p), int(cap)))
+        rec = [{f: getattr(first[i], f) for f in ("exon", "sample", "state", "observed", "total", "got", "want")}
+               for i in range(min(int(cap), nbad.value))]
+        return {"compared": ncmp.value, "beyond": nbad.value, "max_rel": mr.value, "max_abs": ma.value, "first": rec}
+
+    def emit_tables(self, sample):
+        """emit mode 1: (Ly, Lr, obs table [Ly][3], ref table [Lr][3], tot table [Ly + Lr][3]) of one sample, as the last run built them"""
+        dims = (C.c_int32 * 2)()
+        check(lib().ed_batch_copy_emit_tables(self.handle, int(sample), dims, None, 0))
+        ly, lr = int(dims[0]), int(dims[1])
+        ent = np.empty((2 * (ly + lr), 3))
+        if ent.size:
+            check(lib().ed_batch_copy_emit_tables(self.handle, int(sample), dims, _ptr(ent), ent.shape[0]))
+        return ly, lr, ent[:ly], ent[ly:ly + lr], ent[ly + lr:]
+
+    def n_cold_cells(self):
+        n = C.c_int64(0)
+        check(lib().ed_batch_n_cold_cells(self.handle, C.byref(n)))
+        return n.value
+
     def device_pointers(self):
         L = lib()
         return {"loglik": L.ed_batch_loglik(self.handle), "path": L.ed_batch_path(self.handle),

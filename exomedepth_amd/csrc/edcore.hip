@@ -13,6 +13,7 @@
 //   k_fit_*           per-sample beta-binomial fit (aod::betabin's role, R/class_definition.R:118):
 //                     k_fit_moments/start, k_fit_accum/update (per cell)
 //   edfit_hist.inc    k_fit_hist + k_fit_hnewton: the histogram form of that fit, in three geometries (hg8 / hg4 / hg2)
+//   edtab.inc         k_tab_* + k_emit_tab: the table-driven emission mode (log-gamma difference tables per sample and state)
 //   edfused.inc       k_emit_viterbi: emissions + Viterbi in one kernel (optional mode)
 //   edrefset.inc      select.reference.set (R/optimize_reference_set.R:53-148)
 //   edbins.inc        phi.bins > 1 (R/class_definition.R:120-147)
@@ -37,6 +38,7 @@
 #include "../../include/exomedepth_amd.h"
 #include "ed_sf_dev.hpp"
 #include "ed_fit_dev.hpp"
+#include "ed_dtab.h"
 
 #define ED_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -964,6 +966,7 @@ k_tb_paths(const uint32_t* __restrict__ bpq, const int32_t* __restrict__ chrom_o
 
 }  // namespace
 
+#include "edtab.inc"
 #include "edfused.inc"
 
 namespace {
@@ -1686,6 +1689,20 @@ struct ed_batch {
   bool keep_loglik = true;   // fused mode only: also write the [E][3][S] likelihood matrix (the S4 `likelihood` slot)
   int fit_hist = 1;          // ed_batch_fit: 1 = iterate on count histograms (one pass over the counts), geometry picked from
                              // the data; 8 / 4 / 2 = that geometry (samples per workgroup of k_fit_hist); 0 = per cell
+  // table-driven emission mode (edtab.inc; ed_batch_set_emit_mode): buffers allocated on the first run in that mode
+  int emit_mode = 0;             // 0: strict (GSL's arithmetic operation for operation), 1: log-gamma difference tables
+  int tab_tw = 16;               // samples per tile of k_emit_tab (16 / 32 / 64)
+  int tab_capY = 4096, tab_capR = 32768;   // longest obs / ref table of a sample (entries); the tot table has their sum
+  double tab_reach = 8.0;        // a table covers this multiple of the sample's mean count (+ 64)
+  int64_t tab_stride = 0;        // entries between the tables of consecutive samples = 2 (capY + capR)
+  double* d_tabs = nullptr;      // [S][tab_stride][3]
+  int2* d_tdims = nullptr;       // [S + 64] (Ly, Lr) per sample
+  unsigned long long* d_tacc = nullptr;   // [3][S] subsampled count sums (k_tab_stats)
+  uint2* d_cold_list = nullptr;  // cells outside their sample's tables
+  unsigned int* d_cold_n = nullptr;
+  unsigned int cold_cap = 0;
+  std::vector<int64_t> seg_t;    // emission segments for k_emit_tab's tile shape (as `seg`)
+  int64_t* d_seg_t = nullptr;
   int fit_mode = 0;          // ed_batch_fit: 0 = maximum likelihood (Newton); 1 = aod::betabin's procedure (Nelder-Mead from the
                              // glm start, optim()'s defaults) on the same histograms -- ed_batch_set_fit_mode
   bool timing = false;
@@ -2205,7 +2222,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   if (!b) return;
   fitwork_free(b->fitw);
   binswork_free(b->binsw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -2325,17 +2342,78 @@ __global__ void k_emit_bins_tab(const int32_t* __restrict__ test, const int32_t*
 constexpr int kBinsRtab = 8192;    // reference counts covered by the table of the depth-binned model's constants (edbins.inc)
 }
 
+// ---- table-driven emission mode (edtab.inc): buffers, segment table, the per-run table build ----
+static int64_t tab_rows_per_wg(int tw) { return 4 * (64 / tw); }
+
+static int tab_setup(ed_batch* b)
+{
+  if (b->d_tabs) return ED_OK;
+  const ed_plan* p = b->plan;
+  const int64_t S = b->S, E = p->E;
+  b->tab_stride = 2 * ((int64_t)b->tab_capY + b->tab_capR);
+  if ((int64_t)b->tab_tw * b->tab_stride * 24 >= ((int64_t)1 << 31))
+    return ed_fail(ED_ERR_INVALID, "emit mode 1: %d samples x %lld table entries x 24 bytes per tile exceed 2^31 (smaller table caps or tile width)",
+                   b->tab_tw, (long long)b->tab_stride);
+  b->cold_cap = (unsigned int)std::min<int64_t>(std::max<int64_t>(E * S / 32, 1 << 16), (int64_t)1 << 28);
+  bool ok = true;
+  auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) ok = false; };
+  A((void**)&b->d_tabs, (size_t)S * b->tab_stride * 24);
+  A((void**)&b->d_tdims, (size_t)(S + 64) * 8);
+  A((void**)&b->d_tacc, (size_t)3 * S * 8);
+  A((void**)&b->d_cold_list, (size_t)b->cold_cap * 8);
+  A((void**)&b->d_cold_n, 16);
+  if (!ok) return ed_fail(ED_ERR_NOMEM, "emit mode 1: cannot allocate the tables (%lld bytes for %lld samples)",
+                          (long long)(S * b->tab_stride * 24), (long long)S);
+  HIP_TRY(hipMemset(b->d_tdims, 0, (size_t)(S + 64) * 8));
+  // segments in job order, workgroups numbered for k_emit_tab's tile (rows x tab_tw samples), as ed_batch_create does for k_emit_batch
+  const int64_t rows = tab_rows_per_wg(b->tab_tw), nsb = (S + b->tab_tw - 1) / b->tab_tw;
+  int64_t blk = 0;
+  b->seg_t.clear();
+  for (auto& jb : b->jobs) {
+    const int c = jb[0];
+    const int64_t eb = p->chrom_off[c], ee = p->chrom_off[c + 1];
+    b->seg_t.push_back(blk); b->seg_t.push_back(eb); b->seg_t.push_back(ee);
+    const int64_t neb = (ee - eb + rows - 1) / rows;
+    blk += (nsb >= 8) ? ((neb + kTabRun - 1) / kTabRun) * (int64_t)kTabRun * 8 * ((nsb + 7) / 8) : neb * nsb;
+  }
+  b->seg_t.push_back(blk); b->seg_t.push_back(0); b->seg_t.push_back(0);
+  HIP_TRY(hipMalloc((void**)&b->d_seg_t, b->seg_t.size() * 8));
+  HIP_TRY(hipMemcpy(b->d_seg_t, b->seg_t.data(), b->seg_t.size() * 8, hipMemcpyHostToDevice));
+  return ED_OK;
+}
+
+// after k_sample_consts: table lengths from a subsampled pass over the counts, then the entries
+static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, hipStream_t st)
+{
+  if (int rc = tab_setup(b)) return rc;
+  const int64_t E = b->plan->E, S = b->S;
+  const int step = E >= 4096 ? 16 : 1;
+  HIP_TRY(hipMemsetAsync(b->d_tacc, 0, (size_t)3 * S * 8, st));
+  if (E > 0)
+    hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
+                       step, b->d_tacc);
+  hipLaunchKernelGGL(k_tab_dims, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, b->d_consts, b->d_cflags, b->d_tacc, S, b->tab_reach, b->tab_capY,
+                     b->tab_capR, b->d_tdims);
+  hipLaunchKernelGGL(k_tab_build, dim3((unsigned)S, 3), dim3(kTabBlock), 0, st, b->d_consts, b->d_tdims, S, b->d_tabs, b->tab_stride);
+  HIP_TRY(hipGetLastError());
+  return ED_OK;
+}
+
 // The per-sample constants (k_sample_consts) and tables (k_emit_tables) of the default model, made AHEAD of ed_batch_run on
 // another stream: they only need (phi, expected), and in the cohort pipeline those come from a fit that finishes in the middle
 // of the previous slab's emission launch -- so the two latency-bound little kernels (0.3 ms) run there instead of standing
 // between two emission launches.  The caller orders `stream_` after the batch's previous emission kernels (they read the
 // tables) and the next ed_batch_run after this work (an event); ed_batch_run then skips the two kernels if it is handed the
 // same parameters.
-static int batch_prepare(ed_batch* b, const double* d_phi, const double* d_expected, double mixture, hipStream_t st)
+static int batch_prepare(ed_batch* b, const double* d_phi, const double* d_expected, double mixture, hipStream_t st,
+                         const int32_t* d_test = nullptr, const int32_t* d_ref = nullptr)
 {
   if (b->fused) return ED_OK;
+  if (b->emit_mode == 1 && (!d_test || !d_ref)) return ED_OK;   // the tables need the counts: made by the run itself
   const int64_t S = b->S;
   hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S, b->d_consts, b->d_cflags);
+  if (b->emit_mode == 1) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
+  else
   hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S, b->d_tab_gl,
                      b->d_tab_lg);
   HIP_TRY(hipGetLastError());
@@ -2352,6 +2430,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   const bool plain = (em.bins == 0 && !em.cov);   // per-sample (phi, expected): k_emit_batch with hoisted constants
   if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_run: NULL argument");
   if (!plain && b->fused) return ed_fail(ED_ERR_STATE, "ed_batch_run_bins / _cov: not available in fused mode");
+  const bool tabm = plain && b->emit_mode == 1 && !b->fused;   // emissions from log-gamma difference tables (edtab.inc)
   HIP_TRY(hipSetDevice(b->plan->device));   // the caller's thread may have another device current (one process, many GPUs)
   hipStream_t st = (hipStream_t)stream_;
   const ed_plan* p = b->plan;
@@ -2373,10 +2452,28 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   if (plain && !ready) {
     hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
                        b->d_consts, b->d_cflags);
-    if (!b->fused)
+    if (tabm) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
+    else if (!b->fused)
       hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S,
                          b->d_tab_gl, b->d_tab_lg);
   }
+  // one emission launch over workgroups [base, base + n) of the mode's numbering
+  const std::vector<int64_t>& segv = tabm ? b->seg_t : b->seg;
+  int* const cold_flag = reinterpret_cast<int*>(b->d_nerr + 1);
+  auto emit_launch = [&](int64_t n, int64_t base) {
+    if (n <= 0) return;
+    if (!tabm) {
+      hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)n), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, b->d_seg, b->n_jobs, base,
+                         S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr, cold_flag);
+      return;
+    }
+    const uint32_t nsb = (uint32_t)((S + b->tab_tw - 1) / b->tab_tw);
+#define ED_TAB_LAUNCH(TW)                                                                                                                \
+    hipLaunchKernelGGL(k_emit_tab<TW>, dim3((unsigned)n), dim3(kTabBlock), 0, st, d_test, d_ref, b->d_tdims, b->d_tabs, b->tab_stride, b->d_seg_t, \
+                       b->n_jobs, base, S, nsb, b->d_loglik, b->d_cold_list, b->d_cold_n, b->cold_cap)
+    if (b->tab_tw == 64) ED_TAB_LAUNCH(64); else if (b->tab_tw == 32) ED_TAB_LAUNCH(32); else if (b->tab_tw == 8) ED_TAB_LAUNCH(8); else if (b->tab_tw == 4) ED_TAB_LAUNCH(4); else ED_TAB_LAUNCH(16);
+#undef ED_TAB_LAUNCH
+  };
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int64_t cells = E * S;
   if (b->fused) {
@@ -2413,7 +2510,8 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       // One launch per group, except that a group following another starts with a short separate launch: the
       // previous group's Viterbi workgroups (side stream) are dispatched into the slots freed at that launch
       // boundary instead of queueing behind this group's thousands of pending workgroups.
-      const int64_t blk0 = b->seg[3 * j0], nblk = plain ? b->seg[3 * j1] - blk0 : 0;
+      const int64_t blk0 = segv[3 * j0], nblk = plain ? segv[3 * j1] - blk0 : 0;
+      if (tabm) HIP_TRY(hipMemsetAsync(b->d_cold_n, 0, 4, st));
       const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
       if (!plain && g == 0)   // one launch over every cell; the Viterbi groups follow it
       {
@@ -2452,11 +2550,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
                              b->d_nerr, ctab, kBinsRtab, b->d_left_out, em.skip, tpw, eblk);
         }
       }
-      int* cold_flag = reinterpret_cast<int*>(b->d_nerr + 1);
-      if (head > 0)
-        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)head), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
-                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr,
-                           cold_flag);
+      emit_launch(head, blk0);
       // single-group mode with a split: [first part][split_ev][rest]; the cut is a multiple of 8 workgroups (XCD numbering)
       int64_t cut = 0;
       if (plain && b->group_off.size() == 2 && b->split_frac > 0.0 && b->split_frac < 1.0 && b->split_ev) {
@@ -2464,17 +2558,15 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         if (cut <= 0 || cut >= nblk) cut = 0;
       }
       if (cut > 0) {
-        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)cut), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags,
-                           b->d_seg, b->n_jobs, blk0, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr,
-                           cold_flag);
+        emit_launch(cut, blk0);
         HIP_TRY(hipEventRecord(b->split_ev, st));
         b->split_recorded = true;
       }
-      if (nblk - head - cut > 0)
-        hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)(nblk - head - cut)), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts,
-                           b->d_cflags, b->d_seg, b->n_jobs, blk0 + head + cut, S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik,
-                           b->d_nerr, cold_flag);
-      if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
+      emit_launch(nblk - head - cut, blk0 + head + cut);
+      if (tabm && nblk > 0)    // the cells outside their sample's tables (returns at once when there are none)
+        hipLaunchKernelGGL(k_tab_cold, dim3(1024), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, b->d_tdims, b->d_cold_list, b->d_cold_n,
+                           b->cold_cap, b->d_seg_t, j0, j1, S, b->d_loglik, b->d_nerr);
+      else if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
         hipLaunchKernelGGL(k_emit_cold, dim3(512), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_seg, j0, j1, S, b->d_loglik,
                            b->d_nerr, cold_flag);
       HIP_TRY(hipEventRecord(b->job_ev[g], st));
@@ -2750,13 +2842,38 @@ ED_EXPORT int ed_batch_set_fit_mode(ed_batch* b, int mode)
   return ED_OK;
 }
 
+ED_EXPORT int ed_batch_set_emit_mode(ed_batch* b, int mode)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  if (mode != 0 && mode != 1) return ed_fail(ED_ERR_INVALID, "ed_batch_set_emit_mode: 0 (strict) or 1 (tables)");
+  if (mode == 1) {
+    HIP_TRY(hipSetDevice(b->plan->device));
+    if (const char* e = getenv("ED_TAB_TW")) { const int tw = atoi(e); if (!b->d_tabs && (tw == 4 || tw == 8 || tw == 16 || tw == 32 || tw == 64)) b->tab_tw = tw; }
+    if (int rc = tab_setup(b)) return rc;
+  }
+  b->emit_mode = mode;
+  b->prepared = false;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_set_emit_tables(ed_batch* b, int32_t cap_obs, int32_t cap_ref, double reach)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  if (b->d_tabs) return ed_fail(ED_ERR_STATE, "ed_batch_set_emit_tables: the tables are already allocated (call before ed_batch_set_emit_mode(batch, 1))");
+  if (cap_obs < 64 || cap_ref < 64 || cap_obs > (1 << 22) || cap_ref > (1 << 22) || (cap_obs & 7) || (cap_ref & 7) || !(reach >= 1.0 && reach <= 1e6))
+    return ed_fail(ED_ERR_INVALID, "ed_batch_set_emit_tables: caps are multiples of 8 in [64, 2^22], reach in [1, 1e6]");
+  b->tab_capY = cap_obs; b->tab_capR = cap_ref; b->tab_reach = reach;
+  return ED_OK;
+}
+
 ED_EXPORT int ed_batch_n_emit_launches(const ed_batch* b)
 {
   if (!b) return 0;
   if (b->fused) return 1;
   int n = 0;
   for (size_t g = 0; g + 1 < b->group_off.size(); ++g) {
-    const int64_t nblk = b->seg[3 * b->group_off[g + 1]] - b->seg[3 * b->group_off[g]];
+    const std::vector<int64_t>& segv = (b->emit_mode == 1 && !b->seg_t.empty()) ? b->seg_t : b->seg;
+    const int64_t nblk = segv[3 * b->group_off[g + 1]] - segv[3 * b->group_off[g]];
     const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
     n += (head > 0) + (nblk - head > 0);
   }
@@ -2898,6 +3015,71 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
   *n_compared = (int64_t)c[1];
   const int64_t k = std::min<int64_t>((int64_t)c[2], cap);
   if (k > 0) { if (int rc = ed_d2h(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), b->stream)) return rc; }
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_verify_emissions_tol(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
+                                            const double* d_expected, double mixture, double rel_tol, double abs_tol, int64_t* n_compared,
+                                            int64_t* n_beyond, double* max_rel, double* max_abs, ed_emit_mismatch* first, int64_t cap)
+{
+  if (int rc = batch_ready(b)) return rc;
+  if (!d_test || !d_ref || !d_phi || !d_expected || !n_compared || !n_beyond || cap < 0 || (cap > 0 && !first) || !(rel_tol >= 0) || !(abs_tol >= 0))
+    return ed_fail(ED_ERR_INVALID, "ed_batch_verify_emissions_tol: bad arguments");
+  if ((b->fused && !b->keep_loglik) || !b->d_loglik)
+    return ed_fail(ED_ERR_STATE, "ed_batch_verify_emissions_tol: the likelihood matrix is not kept (ed_batch_keep_loglik)");
+  const int64_t E = b->plan->E, S = b->S;
+  *n_compared = 0; *n_beyond = 0;
+  if (max_rel) *max_rel = 0.0;
+  if (max_abs) *max_abs = 0.0;
+  if (E == 0) return ED_OK;
+  DevBuf dcnt, dfirst;
+  HIP_TRY(dcnt.alloc(40)); HIP_TRY(dfirst.alloc((size_t)cap * sizeof(ed_emit_mismatch)));
+  HIP_TRY(hipMemsetAsync(dcnt.p, 0, 40, b->stream));
+  const int64_t rows_per_block = (int64_t)(kEmitBlock / 64) * kVerifyRun;
+  const int64_t eblk = (E + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(k_emit_verify_tol, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535), (unsigned)((eblk + 65534) / 65535)),
+                     dim3(kEmitBlock), 0, b->stream, d_test, d_ref, d_phi, d_expected, mixture, E, S, b->d_loglik, rel_tol, abs_tol,
+                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap);
+  HIP_TRY(hipGetLastError());
+  unsigned long long c[5] = {0, 0, 0, 0, 0};
+  if (int rc = ed_d2h(c, dcnt.p, 40, b->stream)) return rc;
+  *n_beyond = (int64_t)c[0];
+  *n_compared = (int64_t)c[1];
+  double d;
+  if (max_rel) { std::memcpy(&d, &c[3], 8); *max_rel = d; }
+  if (max_abs) { std::memcpy(&d, &c[4], 8); *max_abs = d; }
+  const int64_t k = std::min<int64_t>((int64_t)c[2], cap);
+  if (k > 0) { if (int rc = ed_d2h(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), b->stream)) return rc; }
+  return ED_OK;
+}
+
+// emit mode 1: one sample's tables as the last run built them (test / diagnostic accessor)
+ED_EXPORT int ed_batch_copy_emit_tables(ed_batch* b, int64_t sample, int32_t dims[2], double* entries, int64_t cap_entries)
+{
+  if (int rc = batch_ready(b)) return rc;
+  if (!dims || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_emit_tables: bad arguments");
+  if (!b->d_tabs || b->emit_mode != 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_emit_tables: the batch does not run emit mode 1");
+  int2 d;
+  if (int rc = ed_d2h(&d, b->d_tdims + sample, 8, b->stream)) return rc;
+  dims[0] = d.x; dims[1] = d.y;
+  const int64_t n = std::min<int64_t>(2 * ((int64_t)d.x + d.y), cap_entries);
+  if (n > 0) {
+    if (!entries) return ed_fail(ED_ERR_INVALID, "NULL output");
+    if (int rc = ed_d2h(entries, b->d_tabs + sample * b->tab_stride * 3, (size_t)n * 24, b->stream)) return rc;
+  }
+  return ED_OK;
+}
+
+// emit mode 1: cells the last emission launch group of the last run handed to the strict arithmetic (outside their sample's tables)
+ED_EXPORT int ed_batch_n_cold_cells(ed_batch* b, int64_t* n_cells)
+{
+  if (int rc = batch_ready(b)) return rc;
+  if (!n_cells) return ed_fail(ED_ERR_INVALID, "NULL output");
+  *n_cells = 0;
+  if (!b->d_cold_n) return ED_OK;
+  unsigned int v = 0;
+  if (int rc = ed_d2h(&v, b->d_cold_n, 4, b->stream)) return rc;
+  *n_cells = (int64_t)v;
   return ED_OK;
 }
 

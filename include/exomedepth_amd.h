@@ -272,6 +272,34 @@ int ed_batch_verify_emissions(ed_batch* batch, const int32_t* d_test, const int3
                               const double* d_expected, double mixture, int64_t* n_compared, int64_t* n_mismatch,
                               ed_emit_mismatch* first, int64_t cap);
 
+/* Emission mode of ed_batch_run (default model: per-sample phi and expected).
+ *   0 (default) "strict"  every log-Beta through GSL's evaluation routes operation for operation (reference src/beta.c:49-114,
+ *               src/VP_gamma.c): bit-identical to the CPU checker's portable flavour; ~1 140 binary64 instructions per cell.
+ *   1 "tables"  log B(x, y) = lgamma(x) + lgamma(y) - lgamma(x + y) (the identity at reference src/beta.c:101-108) turns a cell's
+ *               emission log B(a1 + obs, a2 + tot - obs) - log B(a1, a2) (src/CNV_estimate.cpp:44-50) into
+ *                   D(a1, obs) + D(a2, tot - obs) - D(a1 + a2, tot),   D(x, k) = lgamma(x + k) - lgamma(x) = sum_{i<k} log(x + i),
+ *               three per-(sample, state) tables over the sample's count ranges, built before every run as double-double prefix
+ *               sums of logarithms (each entry within 0.5001 ulp of the exact sum); a cell is three gathers and a compensated
+ *               sum.  Log-likelihoods agree with mode 0 / the reference to ~1e-14 relative (1e-10 is the bar); cells whose counts
+ *               lie beyond their sample's tables, and samples whose parameters the tables do not serve (GSL error events,
+ *               non-positive shape parameters, expected < ~1e-4), go through mode 0's arithmetic -- same bits, same error
+ *               counts.  Not available with phi_bins > 1, covariates or fused mode (those runs stay strict).
+ * ed_batch_set_emit_tables (before the mode is first set): longest obs / ref table of a sample in entries (multiples of 8;
+ * defaults 4096 / 32768; the tot table has their sum; 48 (cap_obs + cap_ref) bytes of HBM per sample) and `reach`: a sample's
+ * tables cover reach x its mean count + 64 (default 8). */
+int ed_batch_set_emit_mode(ed_batch* batch, int mode);
+int ed_batch_set_emit_tables(ed_batch* batch, int32_t cap_obs, int32_t cap_ref, double reach);
+/* Tolerance form of ed_batch_verify_emissions: |matrix - per-cell evaluation| <= max(abs_tol, rel_tol |per-cell value|) (NaN matches
+ * NaN).  n_beyond counts values outside it; max_rel / max_abs (optional) the largest differences seen among finite values. */
+int ed_batch_verify_emissions_tol(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
+                                  const double* d_expected, double mixture, double rel_tol, double abs_tol, int64_t* n_compared,
+                                  int64_t* n_beyond, double* max_rel, double* max_abs, ed_emit_mismatch* first, int64_t cap);
+/* emit mode 1 diagnostics: one sample's tables as the last run built them -- dims = (Ly, Lr); entries [2 (Ly + Lr)][3]: the obs
+ * table (Ly entries), the ref table (Lr), the tot table (Ly + Lr), each entry (deletion, normal, duplication) -- and the number
+ * of cells the last run's (last group of) emissions handed to the strict arithmetic. */
+int ed_batch_copy_emit_tables(ed_batch* batch, int64_t sample, int32_t dims[2], double* entries, int64_t cap_entries);
+int ed_batch_n_cold_cells(ed_batch* batch, int64_t* n_cells);
+
 /* Per-stage device times of the last ed_batch_run / ed_batch_fit, measured with HIP events on the
  * stream the kernels were launched on (enable before the run; costs nothing when disabled).
  * ms[]: 0 sample constants, 1 emissions, 2 Viterbi (forward + trace-back + call count),
@@ -397,6 +425,7 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *                      ed_cohort_copy_bins_params / ed_cohort_copy_bins.
  *   "bins_pieces"      phi_bins > 1, pipelined: launches the emission kernel of a slab is cut into (default 10): the next slab's fit is
  *                      a chain of kernels whose workgroups need a whole CU each and only get one where a launch ends
+ *   "emit_mode"        0 (default) strict, 1 tables: ed_batch_set_emit_mode for every slab (phi_bins must be 1)
  *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
  *   "tables_early"     1: a slab's per-sample constants and tables are made right behind its fit, on the fit stream; 0 (default):
  *                      between two emission launches (the same work either way: measured equal)

@@ -25,6 +25,7 @@
 #include <time.h>
 
 #include "../exomedepth_amd/csrc/ed_pmath.h"
+#include "../exomedepth_amd/csrc/ed_dtab.h"   /* the table-driven emission mode's entry definition (host/device header) */
 #include "../exomedepth_amd/csrc/ed_sing_tables.h"
 
 #define EDO_SUCCESS 0
@@ -132,6 +133,23 @@ EDO_API void edo_plog_v(long n, const double *x, double *out) { for (long i = 0;
 EDO_API void edo_pexp_v(long n, const double *x, double *out) { for (long i = 0; i < n; i++) out[i] = ed_pexp(x[i]); }
 EDO_API void edo_psin_v(long n, const double *x, double *out) { for (long i = 0; i < n; i++) out[i] = ed_psin_0pi(x[i]); }
 EDO_API void edo_psin_any_v(long n, const double *x, double *out) { for (long i = 0; i < n; i++) out[i] = ed_psin_any(x[i]); }
+
+/* the log-gamma difference tables of the table-driven emission mode (exomedepth_amd/csrc/ed_dtab.h), evaluated on the host:
+ * what k_tab_build must hold.  edo_ddlog_v: the double-double logarithm behind them. */
+EDO_API void edo_dtab(double x0, long n, double *out)
+{
+  static const double T[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+  ed_dtab_fill_seq(x0, n, out, &T[0][0]);
+}
+EDO_API void edo_ddlog_v(long n, const double *x, double *hi, double *lo)
+{
+  static const double T[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+  for (long i = 0; i < n; i++) { const ed_dd r = ed_ddlog_t(x[i], &T[0][0]); hi[i] = r.hi; lo[i] = r.lo; }
+}
+EDO_API void edo_dtab_combine_v(long n, const double *d1, const double *d2, const double *d3, double *out)
+{
+  for (long i = 0; i < n; i++) out[i] = ed_dtab_combine(d1[i], d2[i], d3[i]);
+}
 
 EDO_API long edo_lnbeta_v(int flavour, long n, const double *x, const double *y, double *out)
 {

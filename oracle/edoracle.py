@@ -37,6 +37,9 @@ def lib():
         for name in ("edo_plog_v", "edo_pexp_v", "edo_psin_v", "edo_psin_any_v"):
             getattr(L, name).argtypes = [C.c_long, _dp, _dp]
             getattr(L, name).restype = None
+        L.edo_dtab.argtypes = [C.c_double, C.c_long, _dp]
+        L.edo_ddlog_v.argtypes = [C.c_long, _dp, _dp, _dp]
+        L.edo_dtab_combine_v.argtypes = [C.c_long, _dp, _dp, _dp, _dp]
         L.edo_lnbeta_v.argtypes = [C.c_int, C.c_long, _dp, _dp, _dp]
         L.edo_lnbeta_v.restype = C.c_long
         L.edo_sf_v.argtypes = [C.c_int, C.c_int, C.c_long, _dp, _dp, _ip]
@@ -98,6 +101,19 @@ def psin(x):
 
 def psin_any(x):
     x = _f64(x); out = np.empty_like(x); lib().edo_psin_any_v(x.size, x, out); return out
+
+
+def dtab(x0, n):
+    """D(x0, k) = lgamma(x0 + k) - lgamma(x0), k = 0..n-1, as the table-driven emission mode tabulates it (csrc/ed_dtab.h)"""
+    out = np.empty(int(n)); lib().edo_dtab(float(x0), int(n), out); return out
+
+
+def ddlog(x):
+    x = _f64(x); hi = np.empty_like(x); lo = np.empty_like(x); lib().edo_ddlog_v(x.size, x, hi, lo); return hi, lo
+
+
+def dtab_combine(d1, d2, d3):
+    d1 = _f64(d1); d2 = _f64(d2); d3 = _f64(d3); out = np.empty_like(d1); lib().edo_dtab_combine_v(d1.size, d1, d2, d3, out); return out
 
 
 def lnbeta(x, y, flavour=PORTABLE):

@@ -1,0 +1,228 @@
+"""Table-driven emission mode (ed_batch_set_emit_mode(batch, 1); csrc/edtab.inc, csrc/ed_dtab.h) against the checker.
+
+Bars (BASELINE.json north_star): log-likelihoods within 1e-10 relative of the reference's arithmetic -- here the LIBM flavour of
+the checker, which is bit-identical to the reference's compiled special functions (tests/test_oracle_ref.py) -- and Viterbi paths
+/ call tables identical.  The strict mode (mode 0) stays the bit-level reference; cells the tables do not serve must carry its bits.
+"""
+import numpy as np
+import pytest
+
+import exomedepth_amd as ed
+from exomedepth_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-10   # north_star tolerance on log-likelihoods
+ABS_TOL = 1e-12   # ... and near zero
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def close(got, want):
+    both_nan = np.isnan(got) & np.isnan(want)
+    ok = both_nan | (got == want) | (np.abs(got - want) <= np.maximum(ABS_TOL, REL_TOL * np.abs(want)))
+    return ok
+
+
+def run_modes(plan, S, test, ref, phi, p, **tab_opts):
+    out = {}
+    for mode in (0, 1):
+        b = ed.Batch(plan, S)
+        if mode:
+            b.set_emit_mode(1, **tab_opts)
+        b.run(test, ref, phi, p)
+        out[mode] = dict(ll=b.loglik(), path=b.path(), calls=b.calls(), nerr=b.n_gsl_errors(), batch=b)
+    return out
+
+
+def test_tables_equal_the_host_definition(edlib, oracle):
+    """k_tab_build (parallel double-double scan) holds what csrc/ed_dtab.h defines (sequential, compiled by gcc into the checker)."""
+    E, S = 3000, 40
+    chrom_off, start, end = synth.exon_design(E, 3, 5)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 5, n_segments=2, mean_depth=150.0)
+    plan = ed.Plan(chrom_off, start, end)
+    b = ed.Batch(plan, S)
+    b.set_emit_mode(1)
+    b.run(test, ref, phi, p)
+    n_diff = n_all = 0
+    for s in (0, 7, S - 1):
+        ly, lr, t1, t2, t3 = b.emit_tables(s)
+        assert ly >= 64 and lr >= 64 and ly % 8 == 0 and lr % 8 == 0
+        assert t3.shape[0] == ly + lr
+        e = p[s]
+        sd2 = phi[s] * e * (1 - e)
+        for st, odds in enumerate((0.5, 1.0, 1.5)):
+            ep = e if st == 1 else (e * odds) / ((e * odds + 1) - e)
+            a1 = ((ep * ep) * (1 - ep)) / sd2 - ep        # src/CNV_estimate.cpp:45-46 (sd * sd vs sd2: the device takes sqrt then squares)
+            # the device's a1 / a2 come from k_sample_consts; rebuild them the same way to the last bit
+            sd = np.sqrt((phi[s] * e) * (1.0 - e))
+            a1 = ((ep * ep) * (1 - ep)) / (sd * sd) - ep
+            a2 = ((1 - ep) / ep) * a1
+            for tab, x0 in ((t1, a1), (t2, a2), (t3, a1 + a2)):
+                want = oracle.dtab(x0, tab.shape[0])
+                d = bits(tab[:, st]) != bits(want)
+                n_diff += int(d.sum()); n_all += d.size
+                # a different association of double-double additions may move an entry that sits on a rounding boundary by one ulp
+                assert np.all(np.abs(tab[:, st] - want) <= np.spacing(np.abs(want))), (s, st)
+    assert n_diff <= n_all // 1000, (n_diff, n_all)
+    b.close(); plan.close()
+
+
+def test_tables_mode_against_the_reference_arithmetic(edlib, oracle):
+    """every value within 1e-10 of the LIBM flavour (= the reference's arithmetic); paths and call tables as strict mode's"""
+    E, S, C = 6000, 96, 5
+    chrom_off, start, end = synth.exon_design(E, C, 2)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 2, n_segments=6, mean_depth=90.0)
+    test[:40, :] = 0; ref[:40, :] = 0           # exons without reads
+    test[100, :] = 0                            # obs = 0 over a deep reference
+    ref[101, :] = 0                             # ref = 0
+    plan = ed.Plan(chrom_off, start, end)
+    r = run_modes(plan, S, test, ref, phi, p)
+    ll0, ll1 = r[0]["ll"], r[1]["ll"]
+    assert np.all(close(ll1, ll0))
+    assert np.all(ll1[:40] == 0.0) and not np.signbit(ll1[:40]).any()      # +0 exactly, as the reference's c - c
+    worst = 0.0
+    for s in range(0, S, 5):
+        ell, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.LIBM)
+        got = ll1[:, :, s]
+        assert np.all(close(got, ell)), s
+        nz = ell != 0
+        worst = max(worst, float(np.max(np.abs(got[nz] - ell[nz]) / np.abs(ell[nz]))))
+        epath, ecalls = oracle.callcnvs(ell, chrom_off, start, end)
+        assert np.array_equal(r[1]["path"][:, s].astype(np.int8), epath), s
+    assert worst < 1e-12, worst
+    assert np.array_equal(r[0]["path"], r[1]["path"])
+    assert np.array_equal(r[0]["calls"], r[1]["calls"])
+    assert r[0]["nerr"] == r[1]["nerr"] == 0
+    # the device-side tolerance check agrees
+    v = r[1]["batch"].verify_emissions_tol(test, ref, phi, p, rel_tol=REL_TOL, abs_tol=ABS_TOL)
+    assert v["compared"] == E * S * 3 and v["beyond"] == 0 and v["max_rel"] < 1e-12, v
+    for m in (0, 1):
+        r[m]["batch"].close()
+    plan.close()
+
+
+def test_cells_beyond_the_tables_carry_the_strict_bits(edlib):
+    """tiny tables: most cells are outside them and go through mode 0's arithmetic -- the list, and the full scan when it runs out"""
+    E, S = 4000, 70
+    chrom_off, start, end = synth.exon_design(E, 4, 3)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 3, n_segments=3, mean_depth=120.0)
+    test[5, 3] = -4                      # a negative count: outside every table; NaN + error events as strict mode
+    plan = ed.Plan(chrom_off, start, end)
+    for reach, cap_obs, cap_ref in ((1.0, 64, 64), (1.0, 128, 1024), (8.0, 4096, 32768)):
+        r = run_modes(plan, S, test, ref, phi, p, cap_obs=cap_obs, cap_ref=cap_ref, reach=reach)
+        b = r[1]["batch"]
+        ncold = b.n_cold_cells()
+        ll0, ll1 = r[0]["ll"], r[1]["ll"]
+        out = np.zeros((E, S), dtype=bool)
+        for s in range(S):
+            ly, lr = b.emit_tables(s)[:2]
+            out[:, s] = ~((test[:, s] >= 0) & (test[:, s] < ly) & (ref[:, s] >= 0) & (ref[:, s] < lr))
+        # with one emission launch group the counter is the batch's; with overlap groups it is the last group's: bound it
+        assert ncold <= out.sum() and (out.sum() == 0) == (ncold == 0)
+        sel = np.broadcast_to(out[:, None, :], ll0.shape)
+        assert np.array_equal(bits(ll1[sel]), bits(ll0[sel]))                 # strict bits (NaN payloads included)
+        assert np.all(close(ll1[~sel], ll0[~sel]))
+        assert r[0]["nerr"] == r[1]["nerr"]
+        assert np.array_equal(r[0]["path"], r[1]["path"]) and np.array_equal(r[0]["calls"], r[1]["calls"])
+        for m in (0, 1):
+            r[m]["batch"].close()
+    plan.close()
+
+
+def test_samples_the_tables_do_not_serve(edlib):
+    """phi >= 1 (negative shape parameters), expected outside (0, 1), a tiny expected (ill-conditioned sum), phi = 1e-9 and 1e-4 (the
+    reference's own rounding noise exceeds the bar), NaN: no tables for
+    those samples -- every cell strict, bit for bit, error counts included -- while their neighbours use theirs"""
+    E, S = 1500, 24
+    chrom_off, start, end = synth.exon_design(E, 2, 4)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 4, n_segments=2, mean_depth=60.0)
+    phi = phi.copy(); p = p.copy()
+    phi[1] = 1.5; phi[2] = 1.0; p[3] = 0.0; p[4] = 1.0; p[5] = 1e-7; phi[6] = np.nan; p[7] = -0.2; phi[8] = 0.0; phi[9] = 1e-9; phi[10] = 1e-4; phi[11] = 3e-4
+    plan = ed.Plan(chrom_off, start, end)
+    r = run_modes(plan, S, test, ref, phi, p)
+    b = r[1]["batch"]
+    ll0, ll1 = r[0]["ll"], r[1]["ll"]
+    for s in range(S):
+        ly, lr = b.emit_tables(s)[:2]
+        if s in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            assert (ly, lr) == (0, 0), s
+            assert np.array_equal(bits(ll1[:, :, s]), bits(ll0[:, :, s])), s
+        else:
+            assert ly > 0 and lr > 0, s
+            assert np.all(close(ll1[:, :, s], ll0[:, :, s])), s
+    assert r[0]["nerr"] == r[1]["nerr"] and r[0]["nerr"] > 0
+    assert np.array_equal(r[0]["path"], r[1]["path"]) and np.array_equal(r[0]["calls"], r[1]["calls"])
+    for m in (0, 1):
+        r[m]["batch"].close()
+    plan.close()
+
+
+@pytest.mark.parametrize("S", [1, 15, 16, 17, 130])
+def test_ragged_sample_blocks_and_schedules(edlib, S):
+    """sample counts around the tile width; one emission launch per batch and the overlap groups; a second run on the same batch"""
+    E = 2500
+    chrom_off, start, end = synth.exon_design(E, 6, 9)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 9, n_segments=3, mean_depth=80.0)
+    plan = ed.Plan(chrom_off, start, end)
+    ref_b = ed.Batch(plan, S)
+    ref_b.run(test, ref, phi, p)
+    ll0, path0, calls0 = ref_b.loglik(), ref_b.path(), ref_b.calls()
+    for overlap in (1, 0):
+        b = ed.Batch(plan, S)
+        b.set_viterbi_overlap(overlap)
+        b.set_emit_mode(1)
+        for _ in range(2):
+            b.run(test, ref, phi, p)
+            assert np.all(close(b.loglik(), ll0))
+            assert np.array_equal(b.path(), path0) and np.array_equal(b.calls(), calls0)
+        b.close()
+    ref_b.close(); plan.close()
+
+
+def test_deep_and_shallow_counts(edlib, oracle):
+    """mean depths 3 and 1500 reads per exon: short tables, and tables at their caps with a tail through the strict arithmetic"""
+    E, S = 3000, 32
+    chrom_off, start, end = synth.exon_design(E, 3, 6)
+    plan = ed.Plan(chrom_off, start, end)
+    for depth in (3.0, 1500.0):
+        test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 6, n_segments=3, mean_depth=depth)
+        r = run_modes(plan, S, test, ref, phi, p)
+        assert np.all(close(r[1]["ll"], r[0]["ll"]))
+        for s in (0, S - 1):
+            ell, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.LIBM)
+            assert np.all(close(r[1]["ll"][:, :, s], ell))
+        assert np.array_equal(r[0]["path"], r[1]["path"]) and np.array_equal(r[0]["calls"], r[1]["calls"])
+        for m in (0, 1):
+            r[m]["batch"].close()
+    plan.close()
+
+
+def test_wide_parameter_grid(edlib, oracle):
+    """phi from 1e-6 to 0.9, expected from 1e-3 to 0.999: whatever gets tables is within 1e-10 of the reference's arithmetic,
+    whatever does not carries the strict bits"""
+    rng = np.random.default_rng(21)
+    E, S = 800, 64
+    chrom_off, start, end = synth.exon_design(E, 2, 8)
+    phi = np.exp(rng.uniform(np.log(1e-6), np.log(0.9), S))
+    p = np.concatenate([np.exp(rng.uniform(np.log(1e-3), np.log(0.5), S // 2)), 1 - np.exp(rng.uniform(np.log(1e-3), np.log(0.5), S - S // 2))])
+    tot = rng.poisson(np.exp(rng.uniform(0, np.log(3000.0), (E, S)))).astype(np.int64)
+    test = rng.binomial(tot, p[None, :]).astype(np.int32)
+    ref = (tot - test).astype(np.int32)
+    plan = ed.Plan(chrom_off, start, end)
+    r = run_modes(plan, S, test, ref, phi, p)
+    b = r[1]["batch"]
+    n_tab = 0
+    for s in range(S):
+        ly, lr = b.emit_tables(s)[:2]
+        ell, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.LIBM)
+        assert np.all(close(r[1]["ll"][:, :, s], ell)), (s, phi[s], p[s], ly, lr)
+        if ly == 0:
+            assert np.array_equal(bits(r[1]["ll"][:, :, s]), bits(r[0]["ll"][:, :, s]))
+        n_tab += ly > 0
+    assert n_tab >= S // 3, n_tab
+    for m in (0, 1):
+        r[m]["batch"].close()
+    plan.close()

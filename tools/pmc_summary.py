@@ -3,7 +3,7 @@ import collections, csv, re, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    m = re.match(r"\(anonymous namespace\)::((?:hg\d::)?k_\w+)", k)   # hgN:: = a histogram geometry of the fit
+    m = re.search(r"\(anonymous namespace\)::((?:hg\d::)?k_\w+)", k)   # (search: a template kernel's name starts with its return type)   # hgN:: = a histogram geometry of the fit
     if not m:
         continue
     name = m.group(1)
