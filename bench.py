@@ -355,7 +355,7 @@ def main():
     ap.add_argument("--chroms", type=int, default=24)
     ap.add_argument("--depth", type=float, default=100.0, help="median reads per exon and sample of the synthetic counts (SURVEY.md 8d: 100)")
     ap.add_argument("--fit", type=int, default=1, help="1 (default): the step includes the per-sample dispersion fit (configs[2]); 0: phi given (configs[1] style)")
-    ap.add_argument("--emit-mode", default="strict", choices=["strict", "tables"], help="strict: every log-Beta through GSL's routes operation for "
+    ap.add_argument("--emit-mode", default="strict", choices=["strict", "tables", "tables-sm"], help="strict: every log-Beta through GSL's routes operation for "
                     "operation (bit-identical to the checker); tables: per-(sample, state) log-gamma difference tables, three gathers and a sum "
                     "per cell (csrc/edtab.inc; within 1e-10 of the reference's arithmetic, verified after the timed region)")
     ap.add_argument("--fused", type=int, default=0, help="1: emissions + Viterbi as one kernel (csrc/edfused.inc)")
@@ -495,8 +495,8 @@ def main():
             opts["own_queues"] = args.own_queues
         if args.tables_early >= 0:
             opts["tables_early"] = args.tables_early
-        if args.emit_mode == "tables" and not bins_cohort:
-            opts["emit_mode"] = 1
+        if args.emit_mode != "strict" and not bins_cohort:
+            opts["emit_mode"] = {"tables": 1, "tables-sm": 2}[args.emit_mode]
         if bins_cohort:
             opts["phi_bins"] = args.phi_bins          # the depth-binned model through the same pipeline (option phi_bins)
             if os.environ.get("ED_BENCH_BINS_PIECES"):
@@ -536,8 +536,8 @@ def main():
             b.set_fused(bool(args.fused))
             b.keep_loglik(bool(args.keep_loglik))
             b.set_async_tail(n_batches >= 2)
-            if args.emit_mode == "tables" and plain and not args.fused:
-                b.set_emit_mode(1)
+            if args.emit_mode != "strict" and plain and not args.fused:
+                b.set_emit_mode(args.emit_mode)
             if n_batches >= 2 and args.viterbi_overlap >= 0:
                 b.set_viterbi_overlap(bool(args.viterbi_overlap))
         main_stream = torch.cuda.current_stream()
@@ -669,7 +669,7 @@ def main():
     if world == 1 and args.verify_columns > 0 and plain and not args.fused:      # (N = 1 only, like cpu_baseline: the other ranks would wait)
         verify = verify_against_oracle(ed, eddist, torch, dev, co if use_cohort else None, batches, last_ticket[0] if use_cohort else None,
                                        n_batches, test, ref, phi, p, phi_fit if not use_cohort else None, p_fit if not use_cohort else None,
-                                       bool(args.fit), chrom_off, start, end, args.verify_columns, tables=args.emit_mode == "tables")
+                                       bool(args.fit), chrom_off, start, end, args.verify_columns, tables=args.emit_mode != "strict")
     fit_conc = None
     if world == 1 and args.fit and plain and not args.fused and args.fit_concordance > 0:
         from exomedepth_amd import concordance
@@ -686,7 +686,7 @@ def main():
         workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps)
 
     if rank == 0:
-        kernel = "k_emit_viterbi" if args.fused else (("k_emit_tab" if args.emit_mode == "tables" else "k_emit_batch") if plain else "k_emit_bins")
+        kernel = "k_emit_viterbi" if args.fused else ({"strict": "k_emit_batch", "tables": "k_emit_tab", "tables-sm": "k_emit_tab_sm"}[args.emit_mode] if plain else "k_emit_bins")
         t_emit = stage_ms["emissions"] * 1e-3
         achieved = ALGO_BYTES_PER_CELL * E * S / t_emit / 1e9 if t_emit > 0 else 0.0
         kernel_cells_per_s = (E * S / t_emit) if t_emit else 0.0

@@ -434,7 +434,7 @@ class Batch:
     def set_emit_mode(self, mode, cap_obs=None, cap_ref=None, reach=None):
         """mode 0 / "strict": GSL's arithmetic operation for operation (default); 1 / "tables": log-gamma difference tables per
         (sample, state) -- three gathers and a sum per cell, ~1e-14 relative (see ed_batch_set_emit_mode)."""
-        m = {"strict": 0, "tables": 1}.get(mode, mode)
+        m = {"strict": 0, "tables": 1, "tables-sm": 2}.get(mode, mode)
         if cap_obs is not None or cap_ref is not None or reach is not None:
             check(lib().ed_batch_set_emit_tables(self.handle, int(cap_obs or 4096), int(cap_ref or 32768), float(reach or 8.0)))
         check(lib().ed_batch_set_emit_mode(self.handle, int(m)))

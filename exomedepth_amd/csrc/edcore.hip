@@ -1176,7 +1176,8 @@ __device__ __forceinline__ double signif3(double x)
 __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, const double* __restrict__ loglik,
                             const double* __restrict__ consts, const int32_t* __restrict__ test,
                             const int32_t* __restrict__ ref, const double* __restrict__ expected, int64_t S,
-                            ed_call_info* __restrict__ out, const double* __restrict__ X, int K, const double* __restrict__ beta)
+                            ed_call_info* __restrict__ out, const double* __restrict__ X, int K, const double* __restrict__ beta,
+                            int64_t le, int64_t lst, int64_t ls)   // likelihood element (e, st, s) at e * le + st * lst + s * ls
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ncalls) return;
@@ -1191,8 +1192,8 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
     const int32_t tot = t + ref[e * S + s];
     double lc, ln;
     if (loglik) {
-      lc = loglik[(e * 3 + col) * S + s];
-      ln = loglik[(e * 3 + 1) * S + s];
+      lc = loglik[e * le + col * lst + s * ls];
+      ln = loglik[e * le + lst + s * ls];
     } else {
       int flag = 0;
       lc = edsf::lnbeta(consts[(col * 3 + 0) * S + s] + (double)t, (consts[(col * 3 + 1) * S + s] + (double)tot) - (double)t, &flag) -
@@ -1703,6 +1704,16 @@ struct ed_batch {
   unsigned int cold_cap = 0;
   std::vector<int64_t> seg_t;    // emission segments for k_emit_tab's tile shape (as `seg`)
   int64_t* d_seg_t = nullptr;
+  // emit mode 2 (sample-major form): the counts as [S][E], the likelihood matrix as [S][3][Epad]; the documented [E][3][S] form
+  // (d_loglik) is made from it when an accessor asks (rows_valid)
+  int32_t* d_test_sm = nullptr;
+  int32_t* d_ref_sm = nullptr;
+  double* d_loglik_sm = nullptr;
+  int64_t Epad = 0;
+  std::vector<int64_t> seg_sm;   // segments in blocks of 64 exons (first block, first exon, end exon), job order
+  int2* d_blk_sm = nullptr;      // per block of that numbering: (its first exon, the end of its chromosome)
+  int64_t nblk_sm = 0;
+  bool rows_valid = true;
   int fit_mode = 0;          // ed_batch_fit: 0 = maximum likelihood (Newton); 1 = aod::betabin's procedure (Nelder-Mead from the
                              // glm start, optim()'s defaults) on the same histograms -- ed_batch_set_fit_mode
   bool timing = false;
@@ -2222,7 +2233,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   if (!b) return;
   fitwork_free(b->fitw);
   binswork_free(b->binsw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t, b->d_test_sm, b->d_ref_sm, b->d_loglik_sm, b->d_blk_sm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -2354,14 +2365,14 @@ static int tab_setup(ed_batch* b)
   if ((int64_t)b->tab_tw * b->tab_stride * 24 >= ((int64_t)1 << 31))
     return ed_fail(ED_ERR_INVALID, "emit mode 1: %d samples x %lld table entries x 24 bytes per tile exceed 2^31 (smaller table caps or tile width)",
                    b->tab_tw, (long long)b->tab_stride);
-  b->cold_cap = (unsigned int)std::min<int64_t>(std::max<int64_t>(E * S / 32, 1 << 16), (int64_t)1 << 28);
+  b->cold_cap = (unsigned int)std::min<int64_t>(std::max<int64_t>(E * S / 32, 1 << 16), (int64_t)1 << 28) / kColdLists * kColdLists;
   bool ok = true;
   auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) ok = false; };
   A((void**)&b->d_tabs, (size_t)S * b->tab_stride * 24);
   A((void**)&b->d_tdims, (size_t)(S + 64) * 8);
   A((void**)&b->d_tacc, (size_t)3 * S * 8);
   A((void**)&b->d_cold_list, (size_t)b->cold_cap * 8);
-  A((void**)&b->d_cold_n, 16);
+  A((void**)&b->d_cold_n, (size_t)(kColdLists + 1) * 4);
   if (!ok) return ed_fail(ED_ERR_NOMEM, "emit mode 1: cannot allocate the tables (%lld bytes for %lld samples)",
                           (long long)(S * b->tab_stride * 24), (long long)S);
   HIP_TRY(hipMemset(b->d_tdims, 0, (size_t)(S + 64) * 8));
@@ -2379,6 +2390,59 @@ static int tab_setup(ed_batch* b)
   b->seg_t.push_back(blk); b->seg_t.push_back(0); b->seg_t.push_back(0);
   HIP_TRY(hipMalloc((void**)&b->d_seg_t, b->seg_t.size() * 8));
   HIP_TRY(hipMemcpy(b->d_seg_t, b->seg_t.data(), b->seg_t.size() * 8, hipMemcpyHostToDevice));
+  return ED_OK;
+}
+
+static int tab_setup_sm(ed_batch* b)
+{
+  if (b->d_loglik_sm) return ED_OK;
+  const ed_plan* p = b->plan;
+  const int64_t S = b->S, E = p->E;
+  b->Epad = ((E + 15) / 16) * 16 + 64;    // (k_viterbi_sm loads whole tiles up to three tiles past a chromosome's end)
+  bool ok = true;
+  auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) ok = false; };
+  A((void**)&b->d_test_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
+  A((void**)&b->d_ref_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
+  A((void**)&b->d_loglik_sm, ((size_t)S * 3 * b->Epad + 512) * 8);
+  if (!ok) return ed_fail(ED_ERR_NOMEM, "emit mode 2: cannot allocate the sample-major matrices (E=%lld S=%lld)", (long long)E, (long long)S);
+  HIP_TRY(hipMemset(b->d_loglik_sm, 0, ((size_t)S * 3 * b->Epad + 512) * 8));
+  // Blocks of 64 exons on the ABSOLUTE exon grid, clipped to their chromosome: every block but the first and last of a chromosome
+  // starts at a multiple of 64 exons, so that a wave's three 512-byte stores are whole aligned 128-byte lines of the [S][3][Epad]
+  // matrix (chromosome-relative blocks made nearly every store begin and end with a partial line).
+  int64_t blk = 0;
+  b->seg_sm.clear();
+  std::vector<int2> bm;
+  for (auto& jb : b->jobs) {
+    const int c = jb[0];
+    const int64_t eb = p->chrom_off[c], ee = p->chrom_off[c + 1];
+    b->seg_sm.push_back(blk); b->seg_sm.push_back(eb); b->seg_sm.push_back(ee);
+    for (int64_t q = (eb / 64) * 64; q < ee; q += 64) {
+      bm.push_back(make_int2((int)std::max(q, eb), (int)std::min(q + 64, ee)));
+      ++blk;
+    }
+  }
+  b->seg_sm.push_back(blk); b->seg_sm.push_back(0); b->seg_sm.push_back(0);
+  if (bm.empty()) bm.push_back(make_int2(0, 0));
+  b->nblk_sm = (int64_t)bm.size();
+  HIP_TRY(hipMalloc((void**)&b->d_blk_sm, bm.size() * 8));
+  HIP_TRY(hipMemcpy(b->d_blk_sm, bm.data(), bm.size() * 8, hipMemcpyHostToDevice));
+  return ED_OK;
+}
+
+// emit mode 2: the [E][3][S] form of the likelihood matrix, made from the sample-major one when somebody asks for it
+static int ensure_loglik_rows(ed_batch* b)
+{
+  if (b->rows_valid) return ED_OK;
+  const int64_t E = b->plan->E, S = b->S;
+  if (!b->d_loglik) {
+    if (hipMalloc((void**)&b->d_loglik, (size_t)std::max<int64_t>(E, 1) * 3 * S * 8) != hipSuccess)
+      return ed_fail(ED_ERR_NOMEM, "cannot allocate the [E][3][S] form of the likelihood matrix");
+  }
+  if (E > 0)
+    hipLaunchKernelGGL(k_ll_sm_to_rows, dim3((unsigned)((E + 63) / 64), (unsigned)((S + 63) / 64), 3), dim3(256), 0, b->stream, b->d_loglik_sm, E, b->Epad, S,
+                       b->d_loglik);
+  HIP_TRY(hipGetLastError());
+  b->rows_valid = true;
   return ED_OK;
 }
 
@@ -2409,10 +2473,10 @@ static int batch_prepare(ed_batch* b, const double* d_phi, const double* d_expec
                          const int32_t* d_test = nullptr, const int32_t* d_ref = nullptr)
 {
   if (b->fused) return ED_OK;
-  if (b->emit_mode == 1 && (!d_test || !d_ref)) return ED_OK;   // the tables need the counts: made by the run itself
+  if (b->emit_mode >= 1 && (!d_test || !d_ref)) return ED_OK;   // the tables need the counts: made by the run itself
   const int64_t S = b->S;
   hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S, b->d_consts, b->d_cflags);
-  if (b->emit_mode == 1) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
+  if (b->emit_mode >= 1) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
   else
   hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S, b->d_tab_gl,
                      b->d_tab_lg);
@@ -2430,7 +2494,9 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   const bool plain = (em.bins == 0 && !em.cov);   // per-sample (phi, expected): k_emit_batch with hoisted constants
   if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_run: NULL argument");
   if (!plain && b->fused) return ed_fail(ED_ERR_STATE, "ed_batch_run_bins / _cov: not available in fused mode");
-  const bool tabm = plain && b->emit_mode == 1 && !b->fused;   // emissions from log-gamma difference tables (edtab.inc)
+  const bool tabm = plain && b->emit_mode >= 1 && !b->fused;   // emissions from log-gamma difference tables (edtab.inc)
+  const bool tabsm = tabm && b->emit_mode == 2;                // ... sample-major form: tables in LDS, [S][3][Epad] likelihood matrix
+  b->rows_valid = !tabsm;
   HIP_TRY(hipSetDevice(b->plan->device));   // the caller's thread may have another device current (one process, many GPUs)
   hipStream_t st = (hipStream_t)stream_;
   const ed_plan* p = b->plan;
@@ -2458,13 +2524,27 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
                          b->d_tab_gl, b->d_tab_lg);
   }
   // one emission launch over workgroups [base, base + n) of the mode's numbering
-  const std::vector<int64_t>& segv = tabm ? b->seg_t : b->seg;
+  if (tabsm) { if (int rc = tab_setup_sm(b)) return rc; }
+  if (tabsm && E > 0) {   // the counts sample-major (R's own layout; an entry that takes them that way makes this pass unnecessary)
+    const dim3 tg((unsigned)((E + 63) / 64), (unsigned)((S + 63) / 64));
+    hipLaunchKernelGGL(k_tab_rows_to_cols, tg, dim3(256), 0, st, d_test, E, S, b->d_test_sm);
+    hipLaunchKernelGGL(k_tab_rows_to_cols, tg, dim3(256), 0, st, d_ref, E, S, b->d_ref_sm);
+  }
+  const std::vector<int64_t>& segv = tabsm ? b->seg_sm : (tabm ? b->seg_t : b->seg);
   int* const cold_flag = reinterpret_cast<int*>(b->d_nerr + 1);
   auto emit_launch = [&](int64_t n, int64_t base) {
     if (n <= 0) return;
     if (!tabm) {
       hipLaunchKernelGGL(k_emit_batch, dim3((unsigned)n), dim3(kEmitBlock), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, b->d_seg, b->n_jobs, base,
                          S, (uint32_t)((S + 63) / 64), b->d_tab_gl, b->d_tab_lg, b->d_loglik, b->d_nerr, cold_flag);
+      return;
+    }
+    if (tabsm) {    // n, base: blocks of 64 exons; every sample gets nsplit workgroups that share them
+      int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(16, (512 + S - 1) / S));
+      nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(nsplit, n / 32));
+      const int64_t nwg = ((S + 7) / 8) * 8 * nsplit;
+      hipLaunchKernelGGL(k_emit_tab_sm, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, b->d_test_sm, b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
+                         b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap);
       return;
     }
     const uint32_t nsb = (uint32_t)((S + b->tab_tw - 1) / b->tab_tw);
@@ -2491,7 +2571,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
                          b->d_job_chrom, b->d_nerr);
     if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
   } else {
-    if (!b->d_loglik) {
+    if (!b->d_loglik && !tabsm) {
       if (hipMalloc((void**)&b->d_loglik, (size_t)std::max<int64_t>(E, 1) * 3 * S * 8) != hipSuccess)
         return ed_fail(ED_ERR_NOMEM, "ed_batch_run: cannot allocate the likelihood matrix");
     }
@@ -2511,8 +2591,8 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       // previous group's Viterbi workgroups (side stream) are dispatched into the slots freed at that launch
       // boundary instead of queueing behind this group's thousands of pending workgroups.
       const int64_t blk0 = segv[3 * j0], nblk = plain ? segv[3 * j1] - blk0 : 0;
-      if (tabm) HIP_TRY(hipMemsetAsync(b->d_cold_n, 0, 4, st));
-      const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
+      if (tabm) HIP_TRY(hipMemsetAsync(b->d_cold_n, 0, (size_t)(kColdLists + 1) * 4, st));
+      const int64_t head = tabsm ? ((g > 0 && nblk > 512) ? 128 : 0) : ((g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0);
       if (!plain && g == 0)   // one launch over every cell; the Viterbi groups follow it
       {
         const int64_t eblk = (E + kEmitBlock / 64 - 1) / (kEmitBlock / 64);   // 4 exons x 64 samples per workgroup
@@ -2554,7 +2634,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       // single-group mode with a split: [first part][split_ev][rest]; the cut is a multiple of 8 workgroups (XCD numbering)
       int64_t cut = 0;
       if (plain && b->group_off.size() == 2 && b->split_frac > 0.0 && b->split_frac < 1.0 && b->split_ev) {
-        cut = ((int64_t)((double)nblk * b->split_frac) / 8) * 8;
+        cut = ((int64_t)((double)nblk * b->split_frac) / 8) * 8;     // (mode 2: blocks of 64 exons -- any cut will do)
         if (cut <= 0 || cut >= nblk) cut = 0;
       }
       if (cut > 0) {
@@ -2565,7 +2645,8 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       emit_launch(nblk - head - cut, blk0 + head + cut);
       if (tabm && nblk > 0)    // the cells outside their sample's tables (returns at once when there are none)
         hipLaunchKernelGGL(k_tab_cold, dim3(1024), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, b->d_tdims, b->d_cold_list, b->d_cold_n,
-                           b->cold_cap, b->d_seg_t, j0, j1, S, b->d_loglik, b->d_nerr);
+                           b->cold_cap, b->d_seg_t, j0, j1, S, tabsm ? b->d_loglik_sm : b->d_loglik, b->d_nerr, tabsm ? (int64_t)1 : 3 * S,
+                           tabsm ? b->Epad : S, tabsm ? 3 * b->Epad : (int64_t)1);
       else if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
         hipLaunchKernelGGL(k_emit_cold, dim3(512), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_seg, j0, j1, S, b->d_loglik,
                            b->d_nerr, cold_flag);
@@ -2580,6 +2661,11 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         HIP_TRY(hipStreamWaitEvent(side, b->zero_ev, 0));
       }
       const dim3 gw((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)(j1 - j0));
+      if (tabsm)
+        hipLaunchKernelGGL(k_viterbi_sm, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
+                           side, b->d_loglik_sm, b->Epad, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
+                           b->d_last, b->d_job_off, b->d_job_chrom, j0);
+      else
       hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
                          side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
                          b->d_last, b->d_job_off, b->d_job_chrom, j0);
@@ -2817,7 +2903,12 @@ ED_EXPORT int ed_batch_fit_n_unconverged(ed_batch* b, int64_t* n_unconverged, in
   return ED_OK;
 }
 
-ED_EXPORT const double* ed_batch_loglik(const ed_batch* b) { return (b && (b->keep_loglik || !b->fused)) ? b->d_loglik : nullptr; }
+ED_EXPORT const double* ed_batch_loglik(const ed_batch* b)
+{
+  if (!b || !(b->keep_loglik || !b->fused)) return nullptr;
+  if (!b->rows_valid && ensure_loglik_rows(const_cast<ed_batch*>(b)) != ED_OK) return nullptr;   // (emit mode 2: made on the run's stream)
+  return b->d_loglik;
+}
 
 ED_EXPORT int ed_batch_set_fused(ed_batch* b, int fused)
 {
@@ -2845,11 +2936,13 @@ ED_EXPORT int ed_batch_set_fit_mode(ed_batch* b, int mode)
 ED_EXPORT int ed_batch_set_emit_mode(ed_batch* b, int mode)
 {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
-  if (mode != 0 && mode != 1) return ed_fail(ED_ERR_INVALID, "ed_batch_set_emit_mode: 0 (strict) or 1 (tables)");
-  if (mode == 1) {
+  if (mode != 0 && mode != 1 && mode != 2) return ed_fail(ED_ERR_INVALID, "ed_batch_set_emit_mode: 0 (strict), 1 (tables, exon-major tiles) or 2 (tables, sample-major)");
+  if (mode >= 1) {
     HIP_TRY(hipSetDevice(b->plan->device));
+    if (const char* e = getenv("ED_TAB_REACH")) { if (!b->d_tabs && atof(e) >= 1.0) b->tab_reach = atof(e); }   // (experiments)
     if (const char* e = getenv("ED_TAB_TW")) { const int tw = atoi(e); if (!b->d_tabs && (tw == 4 || tw == 8 || tw == 16 || tw == 32 || tw == 64)) b->tab_tw = tw; }
     if (int rc = tab_setup(b)) return rc;
+    if (mode == 2) { if (int rc = tab_setup_sm(b)) return rc; }
   }
   b->emit_mode = mode;
   b->prepared = false;
@@ -2872,9 +2965,9 @@ ED_EXPORT int ed_batch_n_emit_launches(const ed_batch* b)
   if (b->fused) return 1;
   int n = 0;
   for (size_t g = 0; g + 1 < b->group_off.size(); ++g) {
-    const std::vector<int64_t>& segv = (b->emit_mode == 1 && !b->seg_t.empty()) ? b->seg_t : b->seg;
+    const std::vector<int64_t>& segv = (b->emit_mode == 2 && !b->seg_sm.empty()) ? b->seg_sm : ((b->emit_mode == 1 && !b->seg_t.empty()) ? b->seg_t : b->seg);
     const int64_t nblk = segv[3 * b->group_off[g + 1]] - segv[3 * b->group_off[g]];
-    const int64_t head = (g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0;
+    const int64_t head = b->emit_mode == 2 ? ((g > 0 && nblk > 512) ? 128 : 0) : ((g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0);
     n += (head > 0) + (nblk - head > 0);
   }
   if (b->group_off.size() == 2 && b->split_frac > 0.0 && b->split_frac < 1.0 && b->split_ev) n += 1;
@@ -2962,8 +3055,9 @@ ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int6
     b->info_cap = cap;
   }
   hipLaunchKernelGGL(k_call_info, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, b->stream, b->d_calls, k,
-                     (b->keep_loglik || !b->fused) ? b->d_loglik : (double*)nullptr, b->d_consts, b->last_test, b->last_ref, b->last_expected, b->S, b->d_info,
-                     b->last_cov_X, b->last_cov_K, b->last_cov_beta);
+                     (b->keep_loglik || !b->fused) ? (b->rows_valid ? b->d_loglik : b->d_loglik_sm) : (double*)nullptr, b->d_consts, b->last_test, b->last_ref,
+                     b->last_expected, b->S, b->d_info, b->last_cov_X, b->last_cov_K, b->last_cov_beta, b->rows_valid ? 3 * b->S : (int64_t)1,
+                     b->rows_valid ? b->S : b->Epad, b->rows_valid ? (int64_t)1 : 3 * b->Epad);
   HIP_TRY(hipGetLastError());
   if (int rc = ed_d2h(host_info, b->d_info, (size_t)k * sizeof(ed_call_info), b->stream)) return rc;
   return ED_OK;
@@ -2981,6 +3075,7 @@ ED_EXPORT int ed_batch_copy_loglik(ed_batch* b, double* host_loglik)
 {
   if (int rc = batch_ready(b)) return rc;
   if (!host_loglik) return ed_fail(ED_ERR_INVALID, "NULL output");
+  if (int rc = ensure_loglik_rows(b)) return rc;
   if ((b->fused && !b->keep_loglik) || !b->d_loglik)
     return ed_fail(ED_ERR_STATE, "the likelihood matrix is not kept (ed_batch_keep_loglik)");
   if (int rc = ed_d2h(host_loglik, b->d_loglik, (size_t)b->plan->E * 3 * b->S * 8, b->stream)) return rc;
@@ -2994,6 +3089,7 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
   if (int rc = batch_ready(b)) return rc;
   if (!d_test || !d_ref || !d_phi || !d_expected || !n_compared || !n_mismatch || cap < 0 || (cap > 0 && !first))
     return ed_fail(ED_ERR_INVALID, "ed_batch_verify_emissions: bad arguments");
+  if (int rc = ensure_loglik_rows(b)) return rc;
   if ((b->fused && !b->keep_loglik) || !b->d_loglik)
     return ed_fail(ED_ERR_STATE, "ed_batch_verify_emissions: the likelihood matrix is not kept (ed_batch_keep_loglik)");
   const int64_t E = b->plan->E, S = b->S;
@@ -3025,6 +3121,7 @@ ED_EXPORT int ed_batch_verify_emissions_tol(ed_batch* b, const int32_t* d_test, 
   if (int rc = batch_ready(b)) return rc;
   if (!d_test || !d_ref || !d_phi || !d_expected || !n_compared || !n_beyond || cap < 0 || (cap > 0 && !first) || !(rel_tol >= 0) || !(abs_tol >= 0))
     return ed_fail(ED_ERR_INVALID, "ed_batch_verify_emissions_tol: bad arguments");
+  if (int rc = ensure_loglik_rows(b)) return rc;
   if ((b->fused && !b->keep_loglik) || !b->d_loglik)
     return ed_fail(ED_ERR_STATE, "ed_batch_verify_emissions_tol: the likelihood matrix is not kept (ed_batch_keep_loglik)");
   const int64_t E = b->plan->E, S = b->S;
@@ -3058,7 +3155,7 @@ ED_EXPORT int ed_batch_copy_emit_tables(ed_batch* b, int64_t sample, int32_t dim
 {
   if (int rc = batch_ready(b)) return rc;
   if (!dims || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_emit_tables: bad arguments");
-  if (!b->d_tabs || b->emit_mode != 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_emit_tables: the batch does not run emit mode 1");
+  if (!b->d_tabs || b->emit_mode < 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_emit_tables: the batch does not run a table-driven emit mode");
   int2 d;
   if (int rc = ed_d2h(&d, b->d_tdims + sample, 8, b->stream)) return rc;
   dims[0] = d.x; dims[1] = d.y;
@@ -3077,9 +3174,9 @@ ED_EXPORT int ed_batch_n_cold_cells(ed_batch* b, int64_t* n_cells)
   if (!n_cells) return ed_fail(ED_ERR_INVALID, "NULL output");
   *n_cells = 0;
   if (!b->d_cold_n) return ED_OK;
-  unsigned int v = 0;
-  if (int rc = ed_d2h(&v, b->d_cold_n, 4, b->stream)) return rc;
-  *n_cells = (int64_t)v;
+  std::vector<unsigned int> v((size_t)kColdLists + 1, 0u);
+  if (int rc = ed_d2h(v.data(), b->d_cold_n, v.size() * 4, b->stream)) return rc;
+  for (int i = 0; i < kColdLists; ++i) *n_cells += (int64_t)v[(size_t)i];
   return ED_OK;
 }
 

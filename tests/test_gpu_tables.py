@@ -26,25 +26,30 @@ def close(got, want):
     return ok
 
 
-def run_modes(plan, S, test, ref, phi, p, **tab_opts):
+MODES = (1, 2)     # 1: exon-major tiles, tables through the caches; 2: sample-major, tables in LDS
+
+
+def run_modes(plan, S, test, ref, phi, p, mode=1, **tab_opts):
+    """results of strict mode under key 0 and of table mode `mode` under key 1"""
     out = {}
-    for mode in (0, 1):
+    for key, m in ((0, 0), (1, mode)):
         b = ed.Batch(plan, S)
-        if mode:
-            b.set_emit_mode(1, **tab_opts)
+        if m:
+            b.set_emit_mode(m, **tab_opts)
         b.run(test, ref, phi, p)
-        out[mode] = dict(ll=b.loglik(), path=b.path(), calls=b.calls(), nerr=b.n_gsl_errors(), batch=b)
+        out[key] = dict(ll=b.loglik(), path=b.path(), calls=b.calls(), nerr=b.n_gsl_errors(), batch=b)
     return out
 
 
-def test_tables_equal_the_host_definition(edlib, oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_tables_equal_the_host_definition(edlib, oracle, mode):
     """k_tab_build (parallel double-double scan) holds what csrc/ed_dtab.h defines (sequential, compiled by gcc into the checker)."""
     E, S = 3000, 40
     chrom_off, start, end = synth.exon_design(E, 3, 5)
     test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 5, n_segments=2, mean_depth=150.0)
     plan = ed.Plan(chrom_off, start, end)
     b = ed.Batch(plan, S)
-    b.set_emit_mode(1)
+    b.set_emit_mode(mode)
     b.run(test, ref, phi, p)
     n_diff = n_all = 0
     for s in (0, 7, S - 1):
@@ -70,7 +75,8 @@ def test_tables_equal_the_host_definition(edlib, oracle):
     b.close(); plan.close()
 
 
-def test_tables_mode_against_the_reference_arithmetic(edlib, oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_tables_mode_against_the_reference_arithmetic(edlib, mode, oracle):
     """every value within 1e-10 of the LIBM flavour (= the reference's arithmetic); paths and call tables as strict mode's"""
     E, S, C = 6000, 96, 5
     chrom_off, start, end = synth.exon_design(E, C, 2)
@@ -79,7 +85,7 @@ def test_tables_mode_against_the_reference_arithmetic(edlib, oracle):
     test[100, :] = 0                            # obs = 0 over a deep reference
     ref[101, :] = 0                             # ref = 0
     plan = ed.Plan(chrom_off, start, end)
-    r = run_modes(plan, S, test, ref, phi, p)
+    r = run_modes(plan, S, test, ref, phi, p, mode)
     ll0, ll1 = r[0]["ll"], r[1]["ll"]
     assert np.all(close(ll1, ll0))
     assert np.all(ll1[:40] == 0.0) and not np.signbit(ll1[:40]).any()      # +0 exactly, as the reference's c - c
@@ -104,7 +110,8 @@ def test_tables_mode_against_the_reference_arithmetic(edlib, oracle):
     plan.close()
 
 
-def test_cells_beyond_the_tables_carry_the_strict_bits(edlib):
+@pytest.mark.parametrize("mode", MODES)
+def test_cells_beyond_the_tables_carry_the_strict_bits(edlib, mode):
     """tiny tables: most cells are outside them and go through mode 0's arithmetic -- the list, and the full scan when it runs out"""
     E, S = 4000, 70
     chrom_off, start, end = synth.exon_design(E, 4, 3)
@@ -112,7 +119,7 @@ def test_cells_beyond_the_tables_carry_the_strict_bits(edlib):
     test[5, 3] = -4                      # a negative count: outside every table; NaN + error events as strict mode
     plan = ed.Plan(chrom_off, start, end)
     for reach, cap_obs, cap_ref in ((1.0, 64, 64), (1.0, 128, 1024), (8.0, 4096, 32768)):
-        r = run_modes(plan, S, test, ref, phi, p, cap_obs=cap_obs, cap_ref=cap_ref, reach=reach)
+        r = run_modes(plan, S, test, ref, phi, p, mode, cap_obs=cap_obs, cap_ref=cap_ref, reach=reach)
         b = r[1]["batch"]
         ncold = b.n_cold_cells()
         ll0, ll1 = r[0]["ll"], r[1]["ll"]
@@ -132,7 +139,8 @@ def test_cells_beyond_the_tables_carry_the_strict_bits(edlib):
     plan.close()
 
 
-def test_samples_the_tables_do_not_serve(edlib):
+@pytest.mark.parametrize("mode", MODES)
+def test_samples_the_tables_do_not_serve(edlib, mode):
     """phi >= 1 (negative shape parameters), expected outside (0, 1), a tiny expected (ill-conditioned sum), phi = 1e-9 and 1e-4 (the
     reference's own rounding noise exceeds the bar), NaN: no tables for
     those samples -- every cell strict, bit for bit, error counts included -- while their neighbours use theirs"""
@@ -142,7 +150,7 @@ def test_samples_the_tables_do_not_serve(edlib):
     phi = phi.copy(); p = p.copy()
     phi[1] = 1.5; phi[2] = 1.0; p[3] = 0.0; p[4] = 1.0; p[5] = 1e-7; phi[6] = np.nan; p[7] = -0.2; phi[8] = 0.0; phi[9] = 1e-9; phi[10] = 1e-4; phi[11] = 3e-4
     plan = ed.Plan(chrom_off, start, end)
-    r = run_modes(plan, S, test, ref, phi, p)
+    r = run_modes(plan, S, test, ref, phi, p, mode)
     b = r[1]["batch"]
     ll0, ll1 = r[0]["ll"], r[1]["ll"]
     for s in range(S):
@@ -160,8 +168,9 @@ def test_samples_the_tables_do_not_serve(edlib):
     plan.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("S", [1, 15, 16, 17, 130])
-def test_ragged_sample_blocks_and_schedules(edlib, S):
+def test_ragged_sample_blocks_and_schedules(edlib, S, mode):
     """sample counts around the tile width; one emission launch per batch and the overlap groups; a second run on the same batch"""
     E = 2500
     chrom_off, start, end = synth.exon_design(E, 6, 9)
@@ -173,7 +182,7 @@ def test_ragged_sample_blocks_and_schedules(edlib, S):
     for overlap in (1, 0):
         b = ed.Batch(plan, S)
         b.set_viterbi_overlap(overlap)
-        b.set_emit_mode(1)
+        b.set_emit_mode(mode)
         for _ in range(2):
             b.run(test, ref, phi, p)
             assert np.all(close(b.loglik(), ll0))
@@ -182,14 +191,15 @@ def test_ragged_sample_blocks_and_schedules(edlib, S):
     ref_b.close(); plan.close()
 
 
-def test_deep_and_shallow_counts(edlib, oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_deep_and_shallow_counts(edlib, mode, oracle):
     """mean depths 3 and 1500 reads per exon: short tables, and tables at their caps with a tail through the strict arithmetic"""
     E, S = 3000, 32
     chrom_off, start, end = synth.exon_design(E, 3, 6)
     plan = ed.Plan(chrom_off, start, end)
     for depth in (3.0, 1500.0):
         test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 6, n_segments=3, mean_depth=depth)
-        r = run_modes(plan, S, test, ref, phi, p)
+        r = run_modes(plan, S, test, ref, phi, p, mode)
         assert np.all(close(r[1]["ll"], r[0]["ll"]))
         for s in (0, S - 1):
             ell, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.LIBM)
@@ -200,7 +210,8 @@ def test_deep_and_shallow_counts(edlib, oracle):
     plan.close()
 
 
-def test_wide_parameter_grid(edlib, oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_wide_parameter_grid(edlib, mode, oracle):
     """phi from 1e-6 to 0.9, expected from 1e-3 to 0.999: whatever gets tables is within 1e-10 of the reference's arithmetic,
     whatever does not carries the strict bits"""
     rng = np.random.default_rng(21)
@@ -212,7 +223,7 @@ def test_wide_parameter_grid(edlib, oracle):
     test = rng.binomial(tot, p[None, :]).astype(np.int32)
     ref = (tot - test).astype(np.int32)
     plan = ed.Plan(chrom_off, start, end)
-    r = run_modes(plan, S, test, ref, phi, p)
+    r = run_modes(plan, S, test, ref, phi, p, mode)
     b = r[1]["batch"]
     n_tab = 0
     for s in range(S):
