@@ -358,6 +358,8 @@ def main():
     ap.add_argument("--emit-mode", default="strict", choices=["strict", "tables", "tables-sm"], help="strict: every log-Beta through GSL's routes operation for "
                     "operation (bit-identical to the checker); tables: per-(sample, state) log-gamma difference tables, three gathers and a sum "
                     "per cell (csrc/edtab.inc; within 1e-10 of the reference's arithmetic, verified after the timed region)")
+    ap.add_argument("--counts-layout", type=int, default=0, help="1: the device count matrices are handed over sample-major, [samples][exons] -- "
+                    "the memory image of R's column-major exons x samples matrix (emit mode tables-sm only: no transposition inside the step)")
     ap.add_argument("--fused", type=int, default=0, help="1: emissions + Viterbi as one kernel (csrc/edfused.inc)")
     ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
     ap.add_argument("--phi-bins", type=int, default=1, help="> 1: the depth-binned dispersion model (phi.bins, csrc/edbins.inc); "
@@ -497,6 +499,9 @@ def main():
             opts["tables_early"] = args.tables_early
         if args.emit_mode != "strict" and not bins_cohort:
             opts["emit_mode"] = {"tables": 1, "tables-sm": 2}[args.emit_mode]
+        if args.counts_layout == 1:
+            assert args.emit_mode == "tables-sm" and not bins_cohort, "--counts-layout 1 goes with --emit-mode tables-sm"
+            opts["counts_layout"] = 1
         if bins_cohort:
             opts["phi_bins"] = args.phi_bins          # the depth-binned model through the same pipeline (option phi_bins)
             if os.environ.get("ED_BENCH_BINS_PIECES"):
@@ -505,12 +510,15 @@ def main():
         batches = []
         last_ticket = [-1]
 
+        # what the steps are handed: the [E][S] matrices, or (--counts-layout 1) their sample-major images, made once, outside the timed region
+        test_in, ref_in = (test.t().contiguous(), ref.t().contiguous()) if args.counts_layout == 1 else (test, ref)
+
         def step():
             step_no[0] += 1
             if args.fit:
-                last_ticket[0] = co.submit(test, ref, n_samples=S)
+                last_ticket[0] = co.submit(test_in, ref_in, n_samples=S)
             else:
-                last_ticket[0] = co.submit(test, ref, phi=phi, expected=p, n_samples=S)
+                last_ticket[0] = co.submit(test_in, ref_in, phi=phi, expected=p, n_samples=S)
 
         def last_batch():
             b, _, _ = co.batch(last_ticket[0])
@@ -652,7 +660,7 @@ def main():
             par = (ed.api._RawDevice(pp), ed.api._RawDevice(pe)) if args.fit else (phi, p)
             reset_timing()
             for _ in range(3):
-                last_ticket[0] = co.submit(test, ref, phi=par[0], expected=par[1], n_samples=S)
+                last_ticket[0] = co.submit(test_in, ref_in, phi=par[0], expected=par[1], n_samples=S)
                 co.drain()
             alone_ms = co.stage_ms_total()[0]["emissions"] / 3.0
         else:
@@ -708,7 +716,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
-                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "emit_mode": args.emit_mode, "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "emit_mode": args.emit_mode, "counts_layout": ("[samples][exons]" if args.counts_layout == 1 else "[exons][samples]"), "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
                        "batches_in_flight": n_batches, "driver": ("cohort (ed_cohort_submit: the library's own streams and batch rotation)" if use_cohort else "python (torch streams)"),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered to rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -439,6 +439,10 @@ class Batch:
             check(lib().ed_batch_set_emit_tables(self.handle, int(cap_obs or 4096), int(cap_ref or 32768), float(reach or 8.0)))
         check(lib().ed_batch_set_emit_mode(self.handle, int(m)))
 
+    def set_counts_layout(self, layout):
+        """0: device count matrices are [n_exons][n_samples]; 1: [n_samples][n_exons] (R's column-major matrix; fit + emit mode 2)"""
+        check(lib().ed_batch_set_counts_layout(self.handle, int(layout)))
+
     def verify_emissions_tol(self, test, ref, phi, expected, mixture=1.0, rel_tol=1e-10, abs_tol=1e-12, cap=16):
         """verify_emissions with a tolerance: returns a dict(compared, beyond, max_rel, max_abs, first)."""
         keep = []

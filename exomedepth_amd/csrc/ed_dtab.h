@@ -47,6 +47,21 @@ ED_PM_FN ed_dd ed_dd_add(ed_dd a, ed_dd b)
   return ed_fast_two_sum(s.hi, s.lo);
 }
 
+/* double-double sum without the second renormalisation: absolute error <= 2^-104 (|a| + |b|) -- what a running sum of logarithms
+ * needs (the entries are rounded to binary64 relative to their own size, and |D| >= 2^-40 max|partial sum| wherever it matters) */
+ED_PM_FN ed_dd ed_dd_add_fast(ed_dd a, ed_dd b)
+{
+  ed_dd s = ed_two_sum(a.hi, b.hi);
+  s.lo += a.lo + b.lo;
+  return ed_fast_two_sum(s.hi, s.lo);
+}
+/* round(a + b) of two double-doubles to binary64 (to within 2^-104 of the sum before the rounding) */
+ED_PM_FN double ed_dd_add_hi(ed_dd a, ed_dd b)
+{
+  const ed_dd s = ed_two_sum(a.hi, b.hi);
+  return s.hi + (s.lo + (a.lo + b.lo));
+}
+
 /* log(x) as a double-double, x positive, normal, finite.  T: the 128 x 3 table ED_PM_LOGT_ROWS (row i at T[3 i]).
  *   x = 2^k z, z in [45/64, 90/64); row i = (invc, logc_hi, logc_lo), logc = -log(invc) to ~2^-97
  *   z invc = p + pe exactly (fma), q = p - 1 exactly, r = q + pe as (rh, rl)
@@ -99,7 +114,7 @@ ED_PM_FN void ed_dtab_fill_seq(double x0, int64_t n, double* out, const double* 
   ed_dd acc = ed_dd_make(0.0, 0.0);
   for (int64_t k = 0; k < n; ++k) {
     out[k] = acc.hi;
-    acc = ed_dd_add(acc, ed_ddlog_t(x0 + (double)k, T));
+    acc = ed_dd_add_fast(acc, ed_ddlog_t(x0 + (double)k, T));
   }
 }
 

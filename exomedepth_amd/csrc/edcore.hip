@@ -541,7 +541,7 @@ constexpr int kVerifyRun = 8;
 __global__ void __launch_bounds__(kEmitBlock)
 k_emit_verify(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, const double* __restrict__ phi,
               const double* __restrict__ expected, double mixture, int64_t E, int64_t S, const double* __restrict__ loglik,
-              unsigned long long* __restrict__ counters, ed_emit_mismatch* __restrict__ first, int64_t cap)
+              unsigned long long* __restrict__ counters, ed_emit_mismatch* __restrict__ first, int64_t cap, int64_t ce, int64_t cs)
 {
   const int64_t s_raw = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int64_t e0 = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (kEmitBlock / 64) + (threadIdx.x >> 6)) * kVerifyRun;
@@ -563,8 +563,8 @@ k_emit_verify(const int32_t* __restrict__ test, const int32_t* __restrict__ ref,
       const int64_t e = e0 + k;
       const bool live = live_s && e < E;
       const int64_t ec = e < E ? e : E - 1;
-      const int32_t obs = test[ec * S + s];
-      const int32_t tot = obs + ref[ec * S + s];
+      const int32_t obs = test[ec * ce + s * cs];     // (ce, cs) = (S, 1): counts [E][S]; (1, E): [S][E]
+      const int32_t tot = obs + ref[ec * ce + s * cs];
       int f1 = 0;
       const double v1 = edsf::lnbeta(a1 + (double)obs, (a2 + (double)tot) - (double)obs, &f1);
       const double want = v1 - v0;
@@ -1177,7 +1177,8 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
                             const double* __restrict__ consts, const int32_t* __restrict__ test,
                             const int32_t* __restrict__ ref, const double* __restrict__ expected, int64_t S,
                             ed_call_info* __restrict__ out, const double* __restrict__ X, int K, const double* __restrict__ beta,
-                            int64_t le, int64_t lst, int64_t ls)   // likelihood element (e, st, s) at e * le + st * lst + s * ls
+                            int64_t le, int64_t lst, int64_t ls,   // likelihood element (e, st, s) at e * le + st * lst + s * ls
+                            int64_t ce, int64_t cs)                // count of (e, s) at e * ce + s * cs
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ncalls) return;
@@ -1188,8 +1189,8 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
   double bh = 0, bl = 0, eh = 0, el = 0;
   int64_t obs = 0;
   for (int64_t e = c.start_exon; e <= c.end_exon; ++e) {
-    const int32_t t = test[e * S + s];
-    const int32_t tot = t + ref[e * S + s];
+    const int32_t t = test[e * ce + s * cs];
+    const int32_t tot = t + ref[e * ce + s * cs];
     double lc, ln;
     if (loglik) {
       lc = loglik[e * le + col * lst + s * ls];
@@ -1280,6 +1281,44 @@ k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const 
   }
   double* o = partial + (chunk * kFitQ) * S + s;
   o[0] = sy; o[S] = sn; o[2 * S] = syy; o[3 * S] = cnt; o[4 * S] = 0; o[5 * S] = 0;
+}
+
+// k_fit_moments for sample-major counts ([S][E], `pitch` ints between samples): one workgroup per sample reads every `stride`-th
+// 64-exon piece of its row (coalesced) and leaves its sums as chunk 0 of the partials (k_fit_start is then given one chunk).
+// Exon e of the fit is element e * by of the row (by > 1: subset.for.speed).
+__global__ void __launch_bounds__(256)
+k_fit_moments_sm(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t pitch, int64_t by, int64_t E, int64_t S,
+                 int stride, double* __restrict__ partial)
+{
+  __shared__ double red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t s = blockIdx.x;
+  const int32_t* __restrict__ trow = test + s * pitch;
+  const int32_t* __restrict__ rrow = ref + s * pitch;
+  double sy = 0, sn = 0, syy = 0, cnt = 0;
+  for (int64_t q = (int64_t)wave * stride; q * 64 < E; q += 4 * (int64_t)stride) {
+    const int64_t e = q * 64 + lane;
+    if (e < E) {
+      const int y = trow[e * by];
+      const int n = y + rrow[e * by];
+      if (n > 0) {
+        sy += (double)y; sn += (double)n;
+        syy += ((double)y * (double)y) / (double)n;
+        cnt += 1.0;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sy += __shfl_xor(sy, d, 64); sn += __shfl_xor(sn, d, 64); syy += __shfl_xor(syy, d, 64); cnt += __shfl_xor(cnt, d, 64);
+  }
+  if (lane == 0) { red[wave][0] = sy; red[wave][1] = sn; red[wave][2] = syy; red[wave][3] = cnt; }
+  __syncthreads();
+  if (tid < 4) {
+    const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    partial[(int64_t)tid * S + s] = v;
+  }
+  if (tid == 4 || tid == 5) partial[(int64_t)tid * S + s] = 0.0;
 }
 
 // Sum the per-chunk partials of one quantity set for 64 samples with a 64 x kRedY thread block: thread
@@ -1679,6 +1718,7 @@ struct ed_batch {
   bool last_run_async = false;          // the last run left its tail on `fin` (done_ev marks its end)
   hipStream_t fin = nullptr;
   hipEvent_t done_ev = nullptr, fork_ev = nullptr;
+  int last_layout = 0;                  // counts_layout of the last run's inputs
   const int32_t* last_test = nullptr;   // inputs of the last ed_batch_run (for ed_batch_copy_call_info)
   const int32_t* last_ref = nullptr;
   const double* last_expected = nullptr;
@@ -1691,6 +1731,8 @@ struct ed_batch {
   int fit_hist = 1;          // ed_batch_fit: 1 = iterate on count histograms (one pass over the counts), geometry picked from
                              // the data; 8 / 4 / 2 = that geometry (samples per workgroup of k_fit_hist); 0 = per cell
   // table-driven emission mode (edtab.inc; ed_batch_set_emit_mode): buffers allocated on the first run in that mode
+  int counts_layout = 0;         // 0: count matrices [E][S] (sample-minor); 1: [S][E] (sample-major, R's column-major E x S matrix) --
+                                 // ed_batch_set_counts_layout; layout 1 serves the histogram fit and emit mode 2
   int emit_mode = 0;             // 0: strict (GSL's arithmetic operation for operation), 1: log-gamma difference tables
   int tab_tw = 16;               // samples per tile of k_emit_tab (16 / 32 / 64)
   int tab_capY = 4096, tab_capR = 32768;   // longest obs / ref table of a sample (entries); the tot table has their sum
@@ -2453,7 +2495,9 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
   const int64_t E = b->plan->E, S = b->S;
   const int step = E >= 4096 ? 16 : 1;
   HIP_TRY(hipMemsetAsync(b->d_tacc, 0, (size_t)3 * S * 8, st));
-  if (E > 0)
+  if (E > 0 && b->counts_layout == 1)
+    hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc);
+  else if (E > 0)
     hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
                        step, b->d_tacc);
   hipLaunchKernelGGL(k_tab_dims, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, b->d_consts, b->d_cflags, b->d_tacc, S, b->tab_reach, b->tab_capY,
@@ -2497,6 +2541,8 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   const bool tabm = plain && b->emit_mode >= 1 && !b->fused;   // emissions from log-gamma difference tables (edtab.inc)
   const bool tabsm = tabm && b->emit_mode == 2;                // ... sample-major form: tables in LDS, [S][3][Epad] likelihood matrix
   b->rows_valid = !tabsm;
+  const bool cl1 = b->counts_layout == 1;                       // counts handed over sample-major [S][E]
+  if (cl1 && !tabsm) return ed_fail(ED_ERR_STATE, "ed_batch_run: sample-major counts (ed_batch_set_counts_layout(batch, 1)) are served by emit mode 2 only");
   HIP_TRY(hipSetDevice(b->plan->device));   // the caller's thread may have another device current (one process, many GPUs)
   hipStream_t st = (hipStream_t)stream_;
   const ed_plan* p = b->plan;
@@ -2509,7 +2555,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   if (b->ran && b->last_run_async && b->done_ev) HIP_TRY(hipStreamWaitEvent(st, b->done_ev, 0));
   b->stream = tail;
   b->split_recorded = false;
-  b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected;
+  b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected; b->last_layout = b->counts_layout;
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
   HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 16, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
@@ -2525,7 +2571,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   }
   // one emission launch over workgroups [base, base + n) of the mode's numbering
   if (tabsm) { if (int rc = tab_setup_sm(b)) return rc; }
-  if (tabsm && E > 0) {   // the counts sample-major (R's own layout; an entry that takes them that way makes this pass unnecessary)
+  if (tabsm && E > 0 && !cl1) {   // the counts sample-major (R's own layout; with ed_batch_set_counts_layout(batch, 1) they arrive that way)
     const dim3 tg((unsigned)((E + 63) / 64), (unsigned)((S + 63) / 64));
     hipLaunchKernelGGL(k_tab_rows_to_cols, tg, dim3(256), 0, st, d_test, E, S, b->d_test_sm);
     hipLaunchKernelGGL(k_tab_rows_to_cols, tg, dim3(256), 0, st, d_ref, E, S, b->d_ref_sm);
@@ -2543,7 +2589,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(16, (512 + S - 1) / S));
       nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(nsplit, n / 32));
       const int64_t nwg = ((S + 7) / 8) * 8 * nsplit;
-      hipLaunchKernelGGL(k_emit_tab_sm, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, b->d_test_sm, b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
+      hipLaunchKernelGGL(k_emit_tab_sm, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
                          b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap);
       return;
     }
@@ -2646,7 +2692,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       if (tabm && nblk > 0)    // the cells outside their sample's tables (returns at once when there are none)
         hipLaunchKernelGGL(k_tab_cold, dim3(1024), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, b->d_tdims, b->d_cold_list, b->d_cold_n,
                            b->cold_cap, b->d_seg_t, j0, j1, S, tabsm ? b->d_loglik_sm : b->d_loglik, b->d_nerr, tabsm ? (int64_t)1 : 3 * S,
-                           tabsm ? b->Epad : S, tabsm ? 3 * b->Epad : (int64_t)1);
+                           tabsm ? b->Epad : S, tabsm ? 3 * b->Epad : (int64_t)1, cl1 ? (int64_t)1 : S, cl1 ? E : (int64_t)1);
       else if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
         hipLaunchKernelGGL(k_emit_cold, dim3(512), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_seg, j0, j1, S, b->d_loglik,
                            b->d_nerr, cold_flag);
@@ -2783,21 +2829,28 @@ static void fitwork_free(FitWork* w)
 // out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
                        int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0, int fit_mode = 0,
-                       int64_t tmod = 0, int skip_K = 0, int* d_skip_from = nullptr)
+                       int64_t tmod = 0, int skip_K = 0, int* d_skip_from = nullptr, int64_t sm_pitch = 0)
 {
+  // sm_pitch > 0: SAMPLE-MAJOR counts -- column s is the row test[s * sm_pitch + e * trs] (trs = the exon step, 1 or subset.for.speed's);
+  // histogram form only
+  const bool sm = sm_pitch > 0;
+  if (sm && (!use_hist || tmod)) return ed_fail(ED_ERR_STATE, "fit: sample-major counts are fitted on the count histograms only (ed_batch_set_fit_histograms(batch, 0) excludes them)");
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
-  const int64_t nch = nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
+  const int64_t nch = sm ? 1 : nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
   const dim3 grid((unsigned)((S + kWave - 1) / kWave), (unsigned)nblk), block(kWave, kFitSub);
   const dim3 g1((unsigned)((S + 255) / 256)), b1(256);
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
   // (fit mode 1 starts from aod's glm-binomial intercept logit(sum y / sum n) over ALL exons; the Newton fit only needs a rough start)
+  if (sm) hipLaunchKernelGGL(k_fit_moments_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, sm_pitch, trs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial);
+  else
   hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial, tmod);
   HIP_TRY(hipMemsetAsync(w.depth, 0, 4, st));
   hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
   if (fit_mode == 1 && !use_hist) return ed_fail(ED_ERR_STATE, "fit mode 1 (aod-nm) works on the count histograms: ed_batch_set_fit_histograms(batch, 0) excludes it");
   if (use_hist) {
-    if (tcs != 1 || trs != rrs) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
+    if (!sm && (tcs != 1 || trs != rrs)) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
+    const int64_t cell_rs = sm ? trs : rrs, cell_cs = sm ? sm_pitch : 1;   // element (e, s) of the counts at e * cell_rs + s * cell_cs
     if (int rc = w.alloc_hist()) return rc;
     // Which geometries to launch: the one asked for (tests), else the one the previous fit's depth points to, else
     // (first fit of this workspace) all three.  The kernels themselves decide which of the launched ones runs, from
@@ -2806,7 +2859,10 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     const int launched = use_hist > 1 ? fit_hist_bit(use_hist) : (hint < 0 ? 7 : fit_hist_bit(fit_hist_geometry(hint)));
     HIP_TRY(hipMemcpyAsync(w.h_depth, w.depth, 4, hipMemcpyDeviceToHost, st));
 #define ED_FIT_HIST(NS, CAP)                                                                                                       \
-    if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
+    if ((launched & fit_hist_bit(NS::kHistId)) && sm)                                                                          \
+      hipLaunchKernelGGL(NS::k_fit_hist_sm, dim3((unsigned)S), dim3(NS::kHsBlock), 0, st, d_test, d_ref, sm_pitch, trs, E, S, w.hist, w.ov_y, w.ov_r, \
+                         w.ovn, CAP, w.depth, launched);                                                                        \
+    else if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hist, dim3((unsigned)((((S + NS::kHistSamples - 1) / NS::kHistSamples * NS::kHistHalves + 7) / 8) * 8)), \
                          dim3(NS::kHistBlock), 0, st, d_test, d_ref, rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, CAP, w.depth, launched);
     ED_FIT_HIST(hg8, w.cap8) ED_FIT_HIST(hg4, w.cap4) ED_FIT_HIST(hg2, w.cap2)
@@ -2814,8 +2870,8 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
 #define ED_FIT_NM(NS, CAP)                                                                                                         \
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnm, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y,     \
-                         w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 2000 /* optim(control = list(maxit = 2000)) */, d_test, d_ref, rrs,  \
-                         E, w.depth, launched, w.fevals);
+                         w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 2000 /* optim(control = list(maxit = 2000)) */, d_test, d_ref, cell_rs,  \
+                         E, w.depth, launched, w.fevals, cell_cs);
     if (fit_mode == 1) {
       ED_FIT_NM(hg8, w.cap8) ED_FIT_NM(hg4, w.cap4) ED_FIT_NM(hg2, w.cap2)
       hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
@@ -2827,7 +2883,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */, \
-                         d_test, d_ref, rrs, E, w.depth, launched);
+                         d_test, d_ref, cell_rs, E, w.depth, launched, cell_cs);
     ED_FIT_NEWTON(hg8, w.cap8) ED_FIT_NEWTON(hg4, w.cap4) ED_FIT_NEWTON(hg2, w.cap2)
 #undef ED_FIT_NEWTON
     hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
@@ -2872,6 +2928,9 @@ ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int3
   if (b->timing) { if (int rc = fold_fit_time(b)) return rc; }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
   const int64_t rows = (E - 1) / by + 1;
+  if (b->counts_layout == 1) {
+    if (int rc = fit_columns(*b->fitw, d_test, by, 1, d_ref, by, rows, S, d_phi, d_expected, st, b->fit_hist, b->fit_mode, 0, 0, nullptr, E)) return rc;
+  } else
   if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist, b->fit_mode)) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[6], st));
   b->have_fit_time = b->timing;
@@ -2945,6 +3004,15 @@ ED_EXPORT int ed_batch_set_emit_mode(ed_batch* b, int mode)
     if (mode == 2) { if (int rc = tab_setup_sm(b)) return rc; }
   }
   b->emit_mode = mode;
+  b->prepared = false;
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_set_counts_layout(ed_batch* b, int layout)
+{
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  if (layout != 0 && layout != 1) return ed_fail(ED_ERR_INVALID, "ed_batch_set_counts_layout: 0 ([n_exons][n_samples]) or 1 ([n_samples][n_exons])");
+  b->counts_layout = layout;
   b->prepared = false;
   return ED_OK;
 }
@@ -3057,7 +3125,8 @@ ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int6
   hipLaunchKernelGGL(k_call_info, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, b->stream, b->d_calls, k,
                      (b->keep_loglik || !b->fused) ? (b->rows_valid ? b->d_loglik : b->d_loglik_sm) : (double*)nullptr, b->d_consts, b->last_test, b->last_ref,
                      b->last_expected, b->S, b->d_info, b->last_cov_X, b->last_cov_K, b->last_cov_beta, b->rows_valid ? 3 * b->S : (int64_t)1,
-                     b->rows_valid ? b->S : b->Epad, b->rows_valid ? (int64_t)1 : 3 * b->Epad);
+                     b->rows_valid ? b->S : b->Epad, b->rows_valid ? (int64_t)1 : 3 * b->Epad, b->last_layout ? (int64_t)1 : b->S,
+                     b->last_layout ? b->plan->E : (int64_t)1);
   HIP_TRY(hipGetLastError());
   if (int rc = ed_d2h(host_info, b->d_info, (size_t)k * sizeof(ed_call_info), b->stream)) return rc;
   return ED_OK;
@@ -3102,7 +3171,7 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
   const int64_t eblk = (E + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL(k_emit_verify, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535), (unsigned)((eblk + 65534) / 65535)),
                      dim3(kEmitBlock), 0, b->stream, d_test, d_ref, d_phi, d_expected, mixture, E, S, b->d_loglik,
-                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap);
+                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap, b->counts_layout ? (int64_t)1 : S, b->counts_layout ? E : (int64_t)1);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));
   unsigned long long c[3] = {0, 0, 0};
@@ -3136,7 +3205,7 @@ ED_EXPORT int ed_batch_verify_emissions_tol(ed_batch* b, const int32_t* d_test, 
   const int64_t eblk = (E + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL(k_emit_verify_tol, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535), (unsigned)((eblk + 65534) / 65535)),
                      dim3(kEmitBlock), 0, b->stream, d_test, d_ref, d_phi, d_expected, mixture, E, S, b->d_loglik, rel_tol, abs_tol,
-                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap);
+                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap, b->counts_layout ? (int64_t)1 : S, b->counts_layout ? E : (int64_t)1);
   HIP_TRY(hipGetLastError());
   unsigned long long c[5] = {0, 0, 0, 0, 0};
   if (int rc = ed_d2h(c, dcnt.p, 40, b->stream)) return rc;

@@ -275,6 +275,11 @@ int ed_batch_verify_emissions(ed_batch* batch, const int32_t* d_test, const int3
 /* Emission mode of ed_batch_run (default model: per-sample phi and expected).
  *   0 (default) "strict"  every log-Beta through GSL's evaluation routes operation for operation (reference src/beta.c:49-114,
  *               src/VP_gamma.c): bit-identical to the CPU checker's portable flavour; ~1 140 binary64 instructions per cell.
+ *   2 "tables, sample-major"  mode 1's arithmetic (same tables, same values) organised by SAMPLE: a workgroup keeps the hot part of
+ *               one sample's tables in LDS (147 KB = 6 144 entries) and walks that sample's exons -- counts read as [n_samples][n_exons],
+ *               likelihood matrix written as [n_samples][3][n_exons + padding], which the Viterbi kernel of this mode reads through an
+ *               LDS transposition; the documented [n_exons][3][n_samples] form is made when an accessor asks for it.  Mode 1 walks
+ *               [n_exons][n_samples] tiles and gathers the tables through L1/L2, where every gather misses L1: 3x slower.
  *   1 "tables"  log B(x, y) = lgamma(x) + lgamma(y) - lgamma(x + y) (the identity at reference src/beta.c:101-108) turns a cell's
  *               emission log B(a1 + obs, a2 + tot - obs) - log B(a1, a2) (src/CNV_estimate.cpp:44-50) into
  *                   D(a1, obs) + D(a2, tot - obs) - D(a1 + a2, tot),   D(x, k) = lgamma(x + k) - lgamma(x) = sum_{i<k} log(x + i),
@@ -288,6 +293,12 @@ int ed_batch_verify_emissions(ed_batch* batch, const int32_t* d_test, const int3
  * defaults 4096 / 32768; the tot table has their sum; 48 (cap_obs + cap_ref) bytes of HBM per sample) and `reach`: a sample's
  * tables cover reach x its mean count + 64 (default 8). */
 int ed_batch_set_emit_mode(ed_batch* batch, int mode);
+/* Layout of the DEVICE count matrices handed to ed_batch_fit* and ed_batch_run: 0 (default) int32 [n_exons][n_samples]
+ * (sample-minor); 1 int32 [n_samples][n_exons] (sample-major) -- the memory image of R's column-major n_exons x n_samples integer
+ * matrix, i.e. what the reference's user holds (R/class_definition.R:82: test / reference vectors are its columns).  Layout 1 is
+ * served by the histogram fit and by emit mode 2 (which works sample-major throughout: with layout 0 it first transposes the
+ * counts); the depth-binned and covariate models take layout 0. */
+int ed_batch_set_counts_layout(ed_batch* batch, int layout);
 int ed_batch_set_emit_tables(ed_batch* batch, int32_t cap_obs, int32_t cap_ref, double reach);
 /* Tolerance form of ed_batch_verify_emissions: |matrix - per-cell evaluation| <= max(abs_tol, rel_tol |per-cell value|) (NaN matches
  * NaN).  n_beyond counts values outside it; max_rel / max_abs (optional) the largest differences seen among finite values. */
@@ -425,7 +436,9 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *                      ed_cohort_copy_bins_params / ed_cohort_copy_bins.
  *   "bins_pieces"      phi_bins > 1, pipelined: launches the emission kernel of a slab is cut into (default 10): the next slab's fit is
  *                      a chain of kernels whose workgroups need a whole CU each and only get one where a launch ends
- *   "emit_mode"        0 (default) strict, 1 tables: ed_batch_set_emit_mode for every slab (phi_bins must be 1)
+ *   "emit_mode"        0 (default) strict, 1 tables, 2 tables sample-major: ed_batch_set_emit_mode for every slab (phi_bins must be 1)
+ *   "counts_layout"    0 (default): device counts [n_exons][n_samples]; 1: [n_samples][n_exons] (needs emit_mode 2): ed_cohort_submit takes
+ *                      them that way, and host-fed slabs in layout 1 (R's column-major matrix) are uploaded without a transposition
  *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
  *   "tables_early"     1: a slab's per-sample constants and tables are made right behind its fit, on the fit stream; 0 (default):
  *                      between two emission launches (the same work either way: measured equal)

@@ -237,3 +237,93 @@ def test_wide_parameter_grid(edlib, mode, oracle):
     for m in (0, 1):
         r[m]["batch"].close()
     plan.close()
+
+
+def test_sample_major_counts(edlib):
+    """ed_batch_set_counts_layout(1): the counts as [n_samples][n_exons] -- R's column-major matrix as it lies in memory -- through
+    the histogram fit and emit mode 2 without a transposition: the same fit (to its tolerance), and given the same parameters the
+    same likelihood bits, paths, calls and decoration as the [n_exons][n_samples] entry"""
+    E, S = 5000, 100
+    chrom_off, start, end = synth.exon_design(E, 5, 12)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 12, n_segments=4, mean_depth=110.0)
+    test[7, 2] = -1
+    tt, rt = np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)
+    plan = ed.Plan(chrom_off, start, end)
+    a = ed.Batch(plan, S); a.set_emit_mode(2)
+    b = ed.Batch(plan, S); b.set_emit_mode(2); b.set_counts_layout(1)
+    fa = [ed.DeviceArray(np.zeros(S)) for _ in range(2)]
+    fb = [ed.DeviceArray(np.zeros(S)) for _ in range(2)]
+    a.fit(test, ref, fa[0], fa[1]); b.fit(tt, rt, fb[0], fb[1])
+    a.run(test, ref, phi, p); b.run(tt, rt, phi, p)
+    assert np.array_equal(bits(a.loglik()), bits(b.loglik()))
+    assert np.array_equal(a.path(), b.path()) and np.array_equal(a.calls(), b.calls())
+    assert a.n_gsl_errors() == b.n_gsl_errors()
+    ia, ib = a.call_info(), b.call_info()
+    assert np.array_equal(ia, ib)
+    for x, y in zip(fa, fb):
+        x, y = x.to_host(), y.to_host()
+        assert np.all(np.abs(x - y) <= 1e-9 * np.abs(x)), np.max(np.abs(x - y) / np.abs(x))
+    assert a.fit_unconverged()[0] == b.fit_unconverged()[0] == 0
+    # the device-side verification reads the counts in the batch's layout
+    v = b.verify_emissions_tol(tt, rt, phi, p, rel_tol=REL_TOL, abs_tol=ABS_TOL)
+    assert v["compared"] == E * S * 3 and v["beyond"] == 0, v
+    # fit mode 1 (Nelder-Mead on the same histograms) and a strided fit (subset.for.speed)
+    for m in (a, b):
+        from exomedepth_amd._lib import check, lib
+        check(lib().ed_batch_set_fit_mode(m.handle, 1))
+    a.fit(test, ref, fa[0], fa[1]); b.fit(tt, rt, fb[0], fb[1])
+    assert np.all(np.abs(fa[0].to_host() - fb[0].to_host()) <= 5e-3 * fa[0].to_host())
+    for m in (a, b):
+        check(lib().ed_batch_set_fit_mode(m.handle, 0))
+    a.fit(test, ref, fa[0], fa[1], by=7); b.fit(tt, rt, fb[0], fb[1], by=7)
+    assert np.all(np.abs(fa[0].to_host() - fb[0].to_host()) <= 1e-8 * fa[0].to_host())
+    # modes that do not take the layout say so
+    c = ed.Batch(plan, S); c.set_counts_layout(1)
+    with pytest.raises(Exception, match="emit mode 2"):
+        c.run(tt, rt, phi, p)
+    for m in (a, b, c):
+        m.close()
+    plan.close()
+
+
+def test_cohort_pipeline_in_table_modes(edlib):
+    """slabs through the cohort pipeline (two in flight) in emit modes 1 and 2, device counts in both layouts and host-fed slabs in R's
+    layout: the calls of the strict pipeline, the fitted parameters to the fit's tolerance"""
+    E, S, slab = 3000, 96, 32
+    chrom_off, start, end = synth.exon_design(E, 4, 13)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 13, n_segments=4, mean_depth=90.0)
+    plan = ed.Plan(chrom_off, start, end)
+
+    def run(**opts):
+        co = ed.Cohort(plan, slab, 2, **opts)
+        lay = opts.get("counts_layout", 0)
+        out = []
+        tickets = []
+        hold = []
+        for s0 in range(0, S, slab):
+            t, r = test[:, s0:s0 + slab], ref[:, s0:s0 + slab]
+            t = np.ascontiguousarray(t.T if lay else t); r = np.ascontiguousarray(r.T if lay else r)
+            hold.append((ed.DeviceArray(t), ed.DeviceArray(r)))
+            tickets.append(co.submit(hold[-1][0], hold[-1][1], n_samples=slab))
+            if len(tickets) >= 2:
+                out.append(co.results(tickets[-2], slab, path=True))
+        out.append(co.results(tickets[-1], slab, path=True))
+        co.close()
+        return out
+
+    base = run()
+    for opts in ({"emit_mode": 1}, {"emit_mode": 2}, {"emit_mode": 2, "counts_layout": 1}):
+        got = run(**opts)
+        for g, w in zip(got, base):
+            assert np.array_equal(g["path"], w["path"]), opts
+            assert np.array_equal(g["calls"], w["calls"]), opts
+            assert np.all(np.abs(g["phi"] - w["phi"]) <= 1e-9 * w["phi"]), opts
+    # host-fed, R's layout, both wire formats, straight into the sample-major pipeline
+    for wire_dtype in (np.int32, np.uint16):
+        co = ed.Cohort(plan, slab, 2, emit_mode=2, counts_layout=1)
+        res = co.run_host(np.ascontiguousarray(test.T.astype(wire_dtype)), np.ascontiguousarray(ref.T.astype(wire_dtype)), layout=1, want_path=True)
+        co0 = ed.Cohort(plan, slab, 2)
+        res0 = co0.run_host(np.ascontiguousarray(test.T.astype(wire_dtype)), np.ascontiguousarray(ref.T.astype(wire_dtype)), layout=1, want_path=True)
+        assert np.array_equal(res["path"], res0["path"]) and np.array_equal(res["calls"], res0["calls"])
+        co.close(); co0.close()
+    plan.close()
