@@ -213,25 +213,75 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
     return out
 
 
+EMIT_MODES = {"strict": 0, "tables-tile": 1, "tables": 2}
+NOTE_STRICT = ("FP64-VALU-bound kernel (no MFMA applies; SURVEY.md 0.5): the HBM roofline is the formal denominator, "
+               "roofline.valu (rocprofv3 PMC passes taken on this very build of the kernels, else withheld) the meaningful "
+               "one.  kernel_ms: HIP events recorded by the library around the emission launches on the stream they "
+               "run on, averaged over the timed steps; consecutive batches' emissions are back to back on that stream.  "
+               "Traffic above 9 B/cell: the kernel materialises the [E][3][S] f64 likelihood matrix (the reference's S4 "
+               "`likelihood` slot: 33 B/cell algorithmic in that form, SURVEY.md 8d) and gathers per-sample tables")
+NOTE_TABLES = ("table-driven emissions, sample-major (k_emit_tab_sm): ~110 VALU lane-instructions per cell, the hot 85-99 % of a sample's "
+               "log-gamma difference tables in LDS -- a memory-streaming kernel: reads the counts (8 B/cell) and writes the [S][3][E] f64 "
+               "likelihood matrix (24 B/cell) that k_viterbi_sm reads back, i.e. 33 B/cell algorithmic in the materialised form against the "
+               "9 B/cell of `achieved` (SURVEY.md 8d).  kernel_ms: HIP events recorded by the library around the emission launches on the "
+               "stream they run on (two launches per step: the cut the next slab's fit is issued at), live = sharing the chip with the "
+               "previous slab's Viterbi chains and the next slab's fit; kernel_ms_alone = the same launches with the GPU to themselves")
+
+
+def mode_opts(args):
+    """cohort options of the emission mode / count layout the run was asked for"""
+    o = {}
+    if args.emit_mode != "strict":
+        o["emit_mode"] = EMIT_MODES[args.emit_mode]
+    if args.counts_layout == 1:
+        o["counts_layout"] = 1
+    return o
+
+
+def mode_leg(ed, torch, plan, test, ref, S, steps, fit, phi, p, opts):
+    """the headline's steps once more under other cohort options (another emission mode, the other count layout): ms per step"""
+    co = ed.Cohort(plan, S, 2, **opts)
+    if opts.get("counts_layout") == 1:
+        test, ref = test.t().contiguous(), ref.t().contiguous()
+    sub = (lambda: co.submit(test, ref, n_samples=S)) if fit else (lambda: co.submit(test, ref, phi=phi, expected=p, n_samples=S))
+    for _ in range(3):
+        sub()
+    co.drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sub()
+    co.drain()
+    el = time.perf_counter() - t0
+    co.close()
+    return {"ms_per_step": el / steps * 1e3, "value": test.numel() * steps / el, "steps": steps}
+
+
 def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
     """The same steps with the counts coming from HOST memory for every slab (ed_cohort_submit_host: copy stream, device slabs
     double-buffered by the slots, the 16-bit wire format widened on the device): the PCIe-inclusive rate.  Reported beside `value`,
     never instead of it.  Pinned host memory is read by the DMA engine in place; pageable memory goes through the library's pinned
     double buffer (host threads copy chunk k+1 while chunk k is on the link)."""
     dt = np.uint16 if args.wire == 2 else np.int32
+    mo = mode_opts(args)
+    lay = 1 if args.counts_layout == 1 else 0          # host layout = the device's: R's column-major matrices go up as they are
     th, rh = test.cpu().numpy(), ref.cpu().numpy()
+    if lay:
+        th, rh = np.ascontiguousarray(th.T), np.ascontiguousarray(rh.T)
+        ref = ref.t().contiguous()
+    shape = th.shape
     if args.wire == 2 and (th.max() >= 65536 or rh.max() >= 65536):
         return {"value_with_h2d": None, "note": "counts beyond 65535: the 16-bit wire format does not apply"}
     out = {}
     for kind in ("pinned", "pageable"):
         if kind == "pinned":
-            pt, pr = ed.PinnedArray((E, S), dt), ed.PinnedArray((E, S), dt)
+            pt, pr = ed.PinnedArray(shape, dt), ed.PinnedArray(shape, dt)
             pt.array[...] = th; pr.array[...] = rh
             ht, hr = pt.array, pr.array
         else:
             ht, hr = th.astype(dt), rh.astype(dt)
-        co = ed.Cohort(plan, S, max(2, n_batches))
-        sub = (lambda: co.submit_host(ht, hr, 0)) if args.fit else (lambda: co.submit_host(ht, hr, 0, phi=phi, expected=p))
+        co = ed.Cohort(plan, S, max(2, n_batches), **mo)
+        sub = (lambda: co.submit_host(ht, hr, lay)) if args.fit else (lambda: co.submit_host(ht, hr, lay, phi=phi, expected=p))
         for _ in range(max(2, n_batches) + 1):
             sub()
         co.drain()
@@ -248,10 +298,10 @@ def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
             pt.free(); pr.free()
     # the reference's workflow: a sample's reference is the sum of other samples of the cohort, made ON THE DEVICE by
     # ed_cohort_select_reference_sets -- only the test counts cross the link (ed_cohort_submit_host_test)
-    pt = ed.PinnedArray((E, S), dt)
+    pt = ed.PinnedArray(shape, dt)
     pt.array[...] = th
-    co = ed.Cohort(plan, S, max(3, n_batches))      # (three slabs in flight: the upload of slab t+2 starts while slab t's chains still run)
-    sub = (lambda: co.submit_host_test(pt.array, ref, 0)) if args.fit else (lambda: co.submit_host_test(pt.array, ref, 0, phi=phi, expected=p))
+    co = ed.Cohort(plan, S, max(3, n_batches), **mo)      # (three slabs in flight: the upload of slab t+2 starts while slab t's chains still run)
+    sub = (lambda: co.submit_host_test(pt.array, ref, lay)) if args.fit else (lambda: co.submit_host_test(pt.array, ref, lay, phi=phi, expected=p))
     for _ in range(max(3, n_batches) + 1):
         sub()
     co.drain()
@@ -275,7 +325,7 @@ def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
                     "stream while earlier slabs compute; link_GBps = bytes on the link / wall time of the steps"}
 
 
-def workflow_leg(ed, torch, plan, test, start, end, E, S, reps):
+def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0):
     """The reference's workflow for one cohort (vignette/vignette.Rnw:390-431), end to end from host memory: upload the cohort's counts
     once (16-bit, pinned), select.reference.set for every sample against all the others + the aggregate references on the device
     (ed_cohort_select_reference_sets, n.bins.reduced = 10 000 as in the vignette), then new('ExomeDepth') + CallCNVs() for every sample
@@ -289,7 +339,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps):
     stream = torch.cuda.current_stream()
     times = {"upload_ms": [], "reference_sets_ms": [], "calls_ms": [], "total_ms": []}
     n_calls = n_chosen = None
-    co = ed.Cohort(plan, S, 1)
+    co = ed.Cohort(plan, S, 1, **({"emit_mode": emit_mode} if emit_mode else {}))
     ref_t = torch.empty((E, S), dtype=torch.int32, device=test.device)
     for rep in range(reps + 1):
         torch.cuda.synchronize()
@@ -318,17 +368,19 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps):
             **med, "value": E * S / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls}
 
 
-def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps):
+def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps, opts={}):
     """BASELINE configs[1]: 200 000 exons x 64 samples, phi given (no fit) -- the first 64 columns of the batch through the cohort
     pipeline (three slabs in flight: 0.91 ms per slab against 1.07 with two and 1.08-1.2 with four to eight -- at 64 samples a slab is
     ~20 launches on three streams and the host's submission rate is what limits), and one slab at a time (the latency of a lone slab:
     bound by the longest chromosome's chain)."""
     n = 64
     t64, r64 = test[:, :n].contiguous(), ref[:, :n].contiguous()
+    if opts.get("counts_layout") == 1:
+        t64, r64 = t64.t().contiguous(), r64.t().contiguous()
     ph, pe = phi[:n].contiguous(), p[:n].contiguous()
     res = {}
     for name, in_flight in (("pipelined", 3), ("one_at_a_time", 1)):
-        co = ed.Cohort(plan, n, in_flight)
+        co = ed.Cohort(plan, n, in_flight, **opts)
         for _ in range(3):
             co.submit(t64, r64, phi=ph, expected=pe, n_samples=n)
         co.drain()
@@ -355,11 +407,16 @@ def main():
     ap.add_argument("--chroms", type=int, default=24)
     ap.add_argument("--depth", type=float, default=100.0, help="median reads per exon and sample of the synthetic counts (SURVEY.md 8d: 100)")
     ap.add_argument("--fit", type=int, default=1, help="1 (default): the step includes the per-sample dispersion fit (configs[2]); 0: phi given (configs[1] style)")
-    ap.add_argument("--emit-mode", default="strict", choices=["strict", "tables", "tables-sm"], help="strict: every log-Beta through GSL's routes operation for "
-                    "operation (bit-identical to the checker); tables: per-(sample, state) log-gamma difference tables, three gathers and a sum "
-                    "per cell (csrc/edtab.inc; within 1e-10 of the reference's arithmetic, verified after the timed region)")
-    ap.add_argument("--counts-layout", type=int, default=0, help="1: the device count matrices are handed over sample-major, [samples][exons] -- "
-                    "the memory image of R's column-major exons x samples matrix (emit mode tables-sm only: no transposition inside the step)")
+    ap.add_argument("--emit-mode", default="tables", choices=["strict", "tables", "tables-tile"], help="tables (default): per-(sample, state) "
+                    "log-gamma difference tables, three lookups and a sum per cell, sample-major with the tables in LDS (csrc/edtab.inc; "
+                    "within 1e-10 of the reference's arithmetic and the same Viterbi paths: verified after the timed region); strict: "
+                    "every log-Beta through GSL's routes operation for operation (bit-identical to the checker); tables-tile: the tables "
+                    "through L1/L2 on [exons][samples] tiles (diagnostic)")
+    ap.add_argument("--counts-layout", type=int, default=-1, help="1: the device count matrices are handed over sample-major, [samples][exons] -- "
+                    "the memory image of R's column-major exons x samples matrix (emit mode tables only: no transposition inside the step); "
+                    "0: [exons][samples]; -1 (default): 1 with --emit-mode tables, else 0")
+    ap.add_argument("--strict-steps", type=int, default=6, help="with --emit-mode tables: timed steps of the same workload in strict mode and in "
+                    "tables mode with [exons][samples] inputs, run after the timed region and reported under extra (0 = skip)")
     ap.add_argument("--fused", type=int, default=0, help="1: emissions + Viterbi as one kernel (csrc/edfused.inc)")
     ap.add_argument("--keep-loglik", type=int, default=1, help="fused mode: 0 = do not materialise the likelihood matrix")
     ap.add_argument("--phi-bins", type=int, default=1, help="> 1: the depth-binned dispersion model (phi.bins, csrc/edbins.inc); "
@@ -403,6 +460,11 @@ def main():
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
     ap.add_argument("--cpu-samples", type=int, default=12, help="columns timed on the host for cpu_baseline (0 = skip)")
     args = ap.parse_args()
+    if args.cov > 0 or args.phi_bins > 1 or args.fused:      # the table-driven mode serves the default model (per-sample phi and expected)
+        args.emit_mode = "strict"
+    if args.counts_layout < 0:
+        args.counts_layout = 1 if args.emit_mode == "tables" else 0
+    assert args.counts_layout == 0 or args.emit_mode == "tables", "--counts-layout 1 goes with --emit-mode tables"
 
     # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and which streams share
     # a queue decides how the pipelined schedule unfolds.  With 6, the fit of the next batch is served in
@@ -497,11 +559,9 @@ def main():
             opts["own_queues"] = args.own_queues
         if args.tables_early >= 0:
             opts["tables_early"] = args.tables_early
-        if args.emit_mode != "strict" and not bins_cohort:
-            opts["emit_mode"] = {"tables": 1, "tables-sm": 2}[args.emit_mode]
-        if args.counts_layout == 1:
-            assert args.emit_mode == "tables-sm" and not bins_cohort, "--counts-layout 1 goes with --emit-mode tables-sm"
-            opts["counts_layout"] = 1
+        if bins_cohort:
+            args.emit_mode, args.counts_layout = "strict", 0
+        opts.update(mode_opts(args))
         if bins_cohort:
             opts["phi_bins"] = args.phi_bins          # the depth-binned model through the same pipeline (option phi_bins)
             if os.environ.get("ED_BENCH_BINS_PIECES"):
@@ -545,7 +605,8 @@ def main():
             b.keep_loglik(bool(args.keep_loglik))
             b.set_async_tail(n_batches >= 2)
             if args.emit_mode != "strict" and plain and not args.fused:
-                b.set_emit_mode(args.emit_mode)
+                b.set_emit_mode(EMIT_MODES[args.emit_mode])
+                b.set_counts_layout(args.counts_layout)
             if n_batches >= 2 and args.viterbi_overlap >= 0:
                 b.set_viterbi_overlap(bool(args.viterbi_overlap))
         main_stream = torch.cuda.current_stream()
@@ -685,16 +746,23 @@ def main():
         fit_conc = concordance.fit_mode_concordance(plan, test[:, :k].contiguous(), ref[:, :k].contiguous())
     config1 = None
     if world == 1 and args.config1_steps > 0 and plain and not args.fused and S >= 64:
-        config1 = config1_leg(ed, torch, plan, test, ref, phi, p, E, args.config1_steps)
+        config1 = config1_leg(ed, torch, plan, test, ref, phi, p, E, args.config1_steps, mode_opts(args))
     staged = None
     if world == 1 and args.stage_inputs and use_cohort:
         staged = staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
     workflow = None
     if world == 1 and args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64:
-        workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps)
+        workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode])
+    other_modes = None
+    if world == 1 and args.strict_steps > 0 and plain and not args.fused and use_cohort and args.emit_mode == "tables":
+        other_modes = {"strict": mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {}),
+                       "tables_counts_exons_x_samples": mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {"emit_mode": 2}),
+                       "note": "the same workload and pipeline, after the timed region: strict = emit mode 0 (GSL's arithmetic operation for operation, "
+                               "bit-identical to the checker: rounds 1-3's headline); tables_counts_exons_x_samples = the headline's mode handed "
+                               "[exons][samples] count matrices (it then transposes them inside every step)"}
 
     if rank == 0:
-        kernel = "k_emit_viterbi" if args.fused else ({"strict": "k_emit_batch", "tables": "k_emit_tab", "tables-sm": "k_emit_tab_sm"}[args.emit_mode] if plain else "k_emit_bins")
+        kernel = "k_emit_viterbi" if args.fused else ({"strict": "k_emit_batch", "tables-tile": "k_emit_tab", "tables": "k_emit_tab_sm"}[args.emit_mode] if plain else "k_emit_bins")
         t_emit = stage_ms["emissions"] * 1e-3
         achieved = ALGO_BYTES_PER_CELL * E * S / t_emit / 1e9 if t_emit > 0 else 0.0
         kernel_cells_per_s = (E * S / t_emit) if t_emit else 0.0
@@ -730,12 +798,7 @@ def main():
                          "kernel_ms_alone": alone_ms,
                          "frac_alone": (ALGO_BYTES_PER_CELL * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "valu": pmc if pmc else why_not,
-                         "note": "FP64-VALU-bound kernel (no MFMA applies; SURVEY.md 0.5): the HBM roofline is the formal denominator, "
-                                 "roofline.valu (rocprofv3 PMC passes taken on this very build of the kernels, else withheld) the meaningful "
-                                 "one.  kernel_ms: HIP events recorded by the library around the emission launches on the stream they "
-                                 "run on, averaged over the timed steps; consecutive batches' emissions are back to back on that stream.  "
-                                 "Traffic above 9 B/cell: the kernel materialises the [E][3][S] f64 likelihood matrix (the reference's S4 "
-                                 "`likelihood` slot: 33 B/cell algorithmic in that form, SURVEY.md 8d) and gathers per-sample tables"},
+                         "note": (NOTE_TABLES if args.emit_mode == "tables" and plain else NOTE_STRICT)},
             "stage_ms": stage_ms,
             "stage_ms_note": "device time between the library's stage events, mean per step.  With 2 batches in flight `viterbi` and "
                              "`call_table` are latencies of the batch's tail on its own streams and `fit` runs on a second stream: "
@@ -743,7 +806,7 @@ def main():
             "n_calls": n_calls,
             "verify": verify,
             "fit_concordance": fit_conc,
-            "extra": {"config1": config1, "workflow": workflow},
+            "extra": {"config1": config1, "workflow": workflow, "other_modes": other_modes},
         }
         if staged:
             out["value_with_h2d"] = staged.pop("value_with_h2d")

@@ -70,7 +70,10 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             # (tools/isa_hazard_scan.py); built only to demonstrate it on hardware next to the fixed library
             "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"],
             # k_fit_hist of the shallow geometry with 4 samples per workgroup: half the LDS, emission workgroups fit beside it
-            "fitlight": ["-DED_HG8_WG=4"]}
+            "fitlight": ["-DED_HG8_WG=4"],
+            # k_emit_tab_sm experiments: plain loads / stores; 512-thread workgroups with half the LDS (two per CU)
+            "smplain": ["-DED_SM_NT=0"], "smntld": ["-DED_SM_NT=1"], "smntst": ["-DED_SM_NT=2"],
+            "sm512": ["-DED_SM_THREADS=512", "-DED_SM_ENTRIES=3072"]}
 
 
 def variant_path(name):
