@@ -73,7 +73,8 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             "fitlight": ["-DED_HG8_WG=4"],
             # k_emit_tab_sm experiments: plain loads / stores; 512-thread workgroups with half the LDS (two per CU)
             "smplain": ["-DED_SM_NT=0"], "smntld": ["-DED_SM_NT=1"], "smntst": ["-DED_SM_NT=2"],
-            "sm512": ["-DED_SM_THREADS=512", "-DED_SM_ENTRIES=3072"]}
+            "sm512": ["-DED_SM_THREADS=512", "-DED_SM_ENTRIES=3072"],
+            "smmask": ["-DED_SM_MASKED=1"], "sm6784": ["-DED_SM_ENTRIES=6784"], "smmask6784": ["-DED_SM_MASKED=1", "-DED_SM_ENTRIES=6784"], "sm4096": ["-DED_SM_ENTRIES=4096"], "sm3584": ["-DED_SM_ENTRIES=3584"], "sm5120": ["-DED_SM_ENTRIES=5120"]}
 
 
 def variant_path(name):

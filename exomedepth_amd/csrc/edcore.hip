@@ -1288,7 +1288,8 @@ k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const 
 // Exon e of the fit is element e * by of the row (by > 1: subset.for.speed).
 __global__ void __launch_bounds__(256)
 k_fit_moments_sm(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t pitch, int64_t by, int64_t E, int64_t S,
-                 int stride, double* __restrict__ partial)
+                 int stride, double* __restrict__ partial, double* __restrict__ eta, double* __restrict__ lam, int* __restrict__ done,
+                 int* __restrict__ depth_max)
 {
   __shared__ double red[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1319,6 +1320,20 @@ k_fit_moments_sm(const int32_t* __restrict__ test, const int32_t* __restrict__ r
     partial[(int64_t)tid * S + s] = v;
   }
   if (tid == 4 || tid == 5) partial[(int64_t)tid * S + s] = 0.0;
+  if (tid == 0) {     // k_fit_start's method-of-moments start for this sample (same arithmetic), saving its launch
+    const double tsy = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0], tsn = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    const double tsyy = ((red[0][2] + red[1][2]) + red[2][2]) + red[3][2], tcnt = ((red[0][3] + red[1][3]) + red[2][3]) + red[3][3];
+    double p = (tsn > 0) ? tsy / tsn : 0.5;
+    p = fmin(fmax(p, 1e-6), 1.0 - 1e-6);
+    const double q = 1.0 - p;
+    const double pearson = (tsyy - 2.0 * p * tsy + p * p * tsn) / (p * q);
+    double phi = (tsn - tcnt > 0) ? (pearson - tcnt) / (tsn - tcnt) : 0.01;
+    phi = fmin(fmax(phi, 1e-4), 0.3);
+    eta[s] = ed_plog(p / q);
+    lam[s] = ed_plog((1.0 - phi) / phi);
+    done[s] = (tcnt < 2.0) ? 1 : 0;
+    if (tcnt > 0) atomicMax(depth_max, (int)fmin(tsn / tcnt, 2.0e9));
+  }
 }
 
 // Sum the per-chunk partials of one quantity set for 64 samples with a 64 x kRedY thread block: thread
@@ -2500,9 +2515,8 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
   else if (E > 0)
     hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
                        step, b->d_tacc);
-  hipLaunchKernelGGL(k_tab_dims, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, b->d_consts, b->d_cflags, b->d_tacc, S, b->tab_reach, b->tab_capY,
-                     b->tab_capR, b->d_tdims);
-  hipLaunchKernelGGL(k_tab_build, dim3((unsigned)S, 3), dim3(kTabBlock), 0, st, b->d_consts, b->d_tdims, S, b->d_tabs, b->tab_stride);
+  hipLaunchKernelGGL(k_tab_build, dim3((unsigned)S, 3), dim3(kTabBlock), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach, b->tab_capY, b->tab_capR,
+                     b->d_tdims, S, b->d_tabs, b->tab_stride);
   HIP_TRY(hipGetLastError());
   return ED_OK;
 }
@@ -2842,11 +2856,13 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   const dim3 gr((unsigned)((S + kWave - 1) / kWave)), br(kWave, kRedY);
   // every pass rewrites all partials, so chunks a strided pass barely touches cannot leave stale sums
   // (fit mode 1 starts from aod's glm-binomial intercept logit(sum y / sum n) over ALL exons; the Newton fit only needs a rough start)
-  if (sm) hipLaunchKernelGGL(k_fit_moments_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, sm_pitch, trs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial);
-  else
-  hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial, tmod);
   HIP_TRY(hipMemsetAsync(w.depth, 0, 4, st));
-  hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
+  if (sm) hipLaunchKernelGGL(k_fit_moments_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, sm_pitch, trs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial,
+                             w.eta, w.lam, w.done, w.depth);
+  else {
+    hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial, tmod);
+    hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
+  }
   if (fit_mode == 1 && !use_hist) return ed_fail(ED_ERR_STATE, "fit mode 1 (aod-nm) works on the count histograms: ed_batch_set_fit_histograms(batch, 0) excludes it");
   if (use_hist) {
     if (!sm && (tcs != 1 || trs != rrs)) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
@@ -2871,10 +2887,9 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnm, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y,     \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 2000 /* optim(control = list(maxit = 2000)) */, d_test, d_ref, cell_rs,  \
-                         E, w.depth, launched, w.fevals, cell_cs);
+                         E, w.depth, launched, w.fevals, cell_cs, d_phi, d_expected);
     if (fit_mode == 1) {
       ED_FIT_NM(hg8, w.cap8) ED_FIT_NM(hg4, w.cap4) ED_FIT_NM(hg2, w.cap2)
-      hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
       HIP_TRY(hipGetLastError());
       return ED_OK;
     }
@@ -2883,10 +2898,9 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */, \
-                         d_test, d_ref, cell_rs, E, w.depth, launched, cell_cs);
+                         d_test, d_ref, cell_rs, E, w.depth, launched, cell_cs, d_phi, d_expected);
     ED_FIT_NEWTON(hg8, w.cap8) ED_FIT_NEWTON(hg4, w.cap4) ED_FIT_NEWTON(hg2, w.cap2)
 #undef ED_FIT_NEWTON
-    hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
     HIP_TRY(hipGetLastError());
     return ED_OK;
   }
