@@ -231,6 +231,8 @@ NOTE_TABLES = ("table-driven emissions, sample-major (k_emit_tab_sm): ~110 VALU 
 def mode_opts(args):
     """cohort options of the emission mode / count layout the run was asked for"""
     o = {}
+    if getattr(args, "fit_mode", 0):
+        o["fit_mode"] = int(args.fit_mode)
     if args.emit_mode != "strict":
         o["emit_mode"] = EMIT_MODES[args.emit_mode]
     if args.counts_layout == 1:
@@ -325,7 +327,7 @@ def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
                     "stream while earlier slabs compute; link_GBps = bytes on the link / wall time of the steps"}
 
 
-def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0):
+def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, world=1, rank=0, eddist=None):
     """The reference's workflow for one cohort (vignette/vignette.Rnw:390-431), end to end from host memory: upload the cohort's counts
     once (16-bit, pinned), select.reference.set for every sample against all the others + the aggregate references on the device
     (ed_cohort_select_reference_sets, n.bins.reduced = 10 000 as in the vignette), then new('ExomeDepth') + CallCNVs() for every sample
@@ -347,7 +349,13 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0):
         dcounts = torch.from_numpy(pin.array.view(np.int16)).to(test.device, non_blocking=True).view(torch.int16).to(torch.int32) & 0xffff
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32, reference_out=ref_t)
+        if world > 1:
+            # a sample-sharded cohort: this rank's columns are S of world * S; every other rank's samples are candidates too -- one
+            # all_gather of the count slabs, then the rank's own tests (exomedepth_amd/dist.py::cohort_reference_sets_sharded)
+            rs = eddist.cohort_reference_sets_sharded(dcounts, S * world, bl, 10000, max_refs=32)
+            ref_t = torch.as_tensor(eddist._DevicePointer(rs["reference"].ptr.value, (E, S), "<i4"), device=test.device)
+        else:
+            rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32, reference_out=ref_t)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         tk = co.submit(dcounts, ref_t, n_samples=S)     # (two half-cohort slabs through the pipeline were tried: 17 ms against 12.7 -- the slicing copies cost more than the overlap gives)
@@ -356,6 +364,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0):
         n_calls = b.n_calls()
         t3 = time.perf_counter()
         n_chosen = float(rs["n_chosen"].mean())
+        checksum = int(np.sum((rs["choice"].astype(np.int64) + 1) * (np.arange(rs["choice"].shape[1], dtype=np.int64) + 1)[None, :]))
         if rep > 0:                                   # (the first repetition allocates)
             for k, v in zip(("upload_ms", "reference_sets_ms", "calls_ms", "total_ms"), (t1 - t0, t2 - t1, t3 - t2, t3 - t0)):
                 times[k].append(v * 1e3)
@@ -365,7 +374,10 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0):
     return {"workload": "one cohort of %d samples x %d exons: counts from pinned host memory (uint16) -> reference sets of every sample against all "
                         "others (n.bins.reduced 10000, <= 32 candidates) + aggregate references on the device -> fit + emissions + Viterbi + calls; "
                         "stages one after the other (one cohort, nothing to overlap with), median of %d" % (S, E, reps),
-            **med, "value": E * S / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls}
+            **med, "value": E * S * world / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls,
+            "ranks": world, "choice_checksum_rank0": checksum,
+            "sharding": (None if world == 1 else "every rank: its own %d columns as tests, all %d as candidates (one all_gather of the count slabs); "
+                                                  "times and counts are rank 0's" % (S, S * world))}
 
 
 def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps, opts={}):
@@ -412,6 +424,10 @@ def main():
                     "within 1e-10 of the reference's arithmetic and the same Viterbi paths: verified after the timed region); strict: "
                     "every log-Beta through GSL's routes operation for operation (bit-identical to the checker); tables-tile: the tables "
                     "through L1/L2 on [exons][samples] tiles (diagnostic)")
+    ap.add_argument("--fit-mode", type=int, default=0, choices=[0, 1], help="0 (default): maximum-likelihood (phi, expected) by Newton's method on the "
+                    "count histograms; 1: aod::betabin's procedure (Nelder-Mead from the glm start, optim()'s tolerances) on the same histograms -- "
+                    "a point inside optim()'s tolerance region, not pinned against aod itself.  The default line carries mode 1's rate "
+                    "under extra.other_modes.fit_mode_1")
     ap.add_argument("--counts-layout", type=int, default=-1, help="1: the device count matrices are handed over sample-major, [samples][exons] -- "
                     "the memory image of R's column-major exons x samples matrix (emit mode tables only: no transposition inside the step); "
                     "0: [exons][samples]; -1 (default): 1 with --emit-mode tables, else 0")
@@ -751,14 +767,17 @@ def main():
     if world == 1 and args.stage_inputs and use_cohort:
         staged = staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
     workflow = None
-    if world == 1 and args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64:
-        workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode])
+    if args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64 and (world == 1 or use_pg):
+        workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode], world, rank, eddist)
     other_modes = None
     if world == 1 and args.strict_steps > 0 and plain and not args.fused and use_cohort and args.emit_mode == "tables":
         other_modes = {"strict": mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {}),
+                       "fit_mode_1": (mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, True, phi, p, {**mode_opts(args), "fit_mode": 1})
+                                      if args.fit and args.fit_mode == 0 else None),
                        "tables_counts_exons_x_samples": mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {"emit_mode": 2}),
                        "note": "the same workload and pipeline, after the timed region: strict = emit mode 0 (GSL's arithmetic operation for operation, "
-                               "bit-identical to the checker: rounds 1-3's headline); tables_counts_exons_x_samples = the headline's mode handed "
+                               "bit-identical to the checker: rounds 1-3's headline); fit_mode_1 = the headline's mode with the dispersion fit by "
+                               "aod::betabin's Nelder-Mead procedure (--fit-mode 1) instead of Newton's method; tables_counts_exons_x_samples = the headline's mode handed "
                                "[exons][samples] count matrices (it then transposes them inside every step)"}
 
     if rank == 0:
@@ -784,7 +803,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
-                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "emit_mode": args.emit_mode, "counts_layout": ("[samples][exons]" if args.counts_layout == 1 else "[exons][samples]"), "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fit_mode": args.fit_mode, "emit_mode": args.emit_mode, "counts_layout": ("[samples][exons]" if args.counts_layout == 1 else "[exons][samples]"), "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
                        "batches_in_flight": n_batches, "driver": ("cohort (ed_cohort_submit: the library's own streams and batch rotation)" if use_cohort else "python (torch streams)"),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered to rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,

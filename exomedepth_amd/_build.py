@@ -71,6 +71,11 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"],
             # k_fit_hist of the shallow geometry with 4 samples per workgroup: half the LDS, emission workgroups fit beside it
             "fitlight": ["-DED_HG8_WG=4"],
+            # host code under the sanitizers (device code is left alone: -fno-gpu-sanitize); tools/sanitize.sh
+            # (no -shared-libsan: the runtime is whatever tools/sanitize.sh preloads -- gcc's stock libasan / libtsan; ROCm's own
+            # ASan runtime intercepts hsa_amd_memory_pool_allocate for DEVICE instrumentation and fails on a plain process)
+            "asan": ["-fsanitize=address,undefined", "-fno-sanitize=vptr,function", "-fno-gpu-sanitize", "-g", "-fno-omit-frame-pointer", "-Wl,--unresolved-symbols=ignore-all"],
+            "tsan": ["-fsanitize=thread", "-fno-gpu-sanitize", "-g", "-fno-omit-frame-pointer", "-Wl,--unresolved-symbols=ignore-all"],
             # k_emit_tab_sm experiments: plain loads / stores; 512-thread workgroups with half the LDS (two per CU)
             "smplain": ["-DED_SM_NT=0"], "smntld": ["-DED_SM_NT=1"], "smntst": ["-DED_SM_NT=2"],
             "sm512": ["-DED_SM_THREADS=512", "-DED_SM_ENTRIES=3072"],

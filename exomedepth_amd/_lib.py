@@ -9,6 +9,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libedcore.so")
+if os.environ.get("ED_LIB_VARIANT"):      # a diagnostic build of the same sources (_build.VARIANTS: sanitizers, experiments); never the default
+    LIB_PATH = os.path.join(HERE, "libedcore_%s.so" % os.environ["ED_LIB_VARIANT"])
 
 ED_OK = 0
 
@@ -88,6 +90,7 @@ SYMBOLS = [
     ("ed_select_reference_set", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     ("ed_select_reference_set_part", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     ("ed_cohort_select_reference_sets", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    ("ed_cohort_select_reference_sets_range", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     ("ed_cohort_select_reference_sets_host", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     ("ed_release_scratch", C.c_int, []),
     ("ed_refset_finalize", C.c_int, [_vp, _i64, C.POINTER(_i32)]),

@@ -2132,9 +2132,10 @@ static hipError_t ed_stream_create(hipStream_t* st, bool own_queue, int device)
 ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples)
 {
   if (!batch || !plan || n_samples <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_create: bad arguments");
-  // 32-bit byte offsets into the per-sample tables (3 * kEmitTab * n_samples entries of 16 bytes) and 28-bit entry numbers
-  if (n_samples > 65536)
-    return ed_fail(ED_ERR_INVALID, "ed_batch_create: %lld samples in one batch; at most 65536 (split the cohort into slabs: ed_cohort_*)",
+  // k_emit_batch reads the per-sample tables through a buffer resource whose size field is 32 bits: 3 * kEmitTab * n_samples entries
+  // of 16 bytes must stay below 2^31 (n_samples <= 43 690), or the entries beyond read as zero
+  if (n_samples > 32768)
+    return ed_fail(ED_ERR_INVALID, "ed_batch_create: %lld samples in one batch; at most 32768 (split the cohort into slabs: ed_cohort_*)",
                    (long long)n_samples);
   if (int rc = require_device()) return rc;
   HIP_TRY(hipSetDevice(plan->device));

@@ -133,3 +133,54 @@ def select_reference_set_sharded(test_counts, reference_counts, bin_length=None,
         nm = names if names is not None else ["X%d" % (i + 1) for i in range(R)]
         return {"reference.choice": [nm[int(merged["ref_index"][0])]], "summary.stats": merged}
     return api.refset_finalize(merged, names)
+
+
+def cohort_reference_sets_sharded(local_counts, n_samples_total, bin_length=None, n_bins_reduced=0, max_refs=32, group=None,
+                                  compute_range=None):
+    """The reference-set stage of the workflow for a SAMPLE-SHARDED cohort (BASELINE configs[3]: 8192 samples over 8 GPUs).
+
+    In the reference every test sample runs select.reference.set against ALL the other samples (vignette/vignette.Rnw:390-402,
+    R/optimize_reference_set.R:100-141), so a rank that owns the columns shard_bounds(S, rank, world) needs the candidates that live
+    on the other ranks.  One `all_gather` of the count slabs gives every rank the whole (E, S) matrix -- 6.5 GB at 200 000 x 8192
+    int32, i.e. each GPU takes in 7/8 of it over its 7 xGMI links (~5.7 GB at a few hundred GB/s: tens of milliseconds, once per
+    cohort; the slabs are (E, S_r) column blocks, so they are gathered as their transposes, contiguous (S_r, E) blocks of the
+    (S, E) matrix, and the result is viewed back) -- and the rank then runs ed_cohort_select_reference_sets_range on ITS tests:
+    a (S_r x S) block of the correlation matrix, its tests' prefixes / fits, and the aggregate references of its own columns,
+    which is exactly what its ed_cohort_submit needs next to its own counts.  No other exchange.
+
+    local_counts: (E, S_r) int32 tensor on the backend's device.  Returns dict(n_chosen (S_r,), choice (S_r, K) with columns of the
+    WHOLE cohort, summary.stats, n.bins, reference: (E, S_r) aggregate references).  compute_range(all_counts, t0, t1) -> that dict:
+    defaults to the GPU path; injectable so that the gather / view logic is testable on the gloo backend without a GPU."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    S = int(n_samples_total)
+    E = int(local_counts.shape[0])
+    t0, t1 = shard_bounds(S, rank, world)
+    assert int(local_counts.shape[1]) == t1 - t0, "local_counts must hold this rank's columns shard_bounds(S, rank, world)"
+    # gather the TRANSPOSED slabs: rank r's (S_r, E) block is rows [lo_r, hi_r) of the (S, E) matrix -- contiguous pieces of one buffer
+    home = local_counts.device
+    # (the gloo backend moves host memory: the slabs go through the host then -- what the 2-ranks-on-one-GPU test and CPU tests do)
+    cdev = home if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = local_counts.t().contiguous().to(cdev)
+    full_t = torch.empty((S, E), dtype=local_counts.dtype, device=cdev)
+    pieces = [full_t[slice(*shard_bounds(S, r, world))] for r in range(world)]
+    if all(p.shape == pieces[0].shape for p in pieces):
+        dist.all_gather_into_tensor(full_t, mine, group=group) if hasattr(dist, "all_gather_into_tensor") and dist.get_backend(group) == "nccl" \
+            else dist.all_gather(pieces, mine, group=group)
+    else:                                   # ragged shards: all_gather wants equal shapes -- pad to the widest
+        width = max(p.shape[0] for p in pieces)
+        pad = torch.zeros((width, E), dtype=mine.dtype, device=mine.device)
+        pad[:mine.shape[0]] = mine
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        for r in range(world):
+            pieces[r].copy_(bufs[r][:pieces[r].shape[0]])
+    all_counts = full_t.to(home).t().contiguous()    # (E, S): the layout the reference-set entry takes
+    del full_t
+    if compute_range is None:
+        return api.cohort_select_reference_sets(all_counts, bin_length, n_bins_reduced, max_refs, want_reference=True, test_range=(t0, t1))
+    return compute_range(all_counts, t0, t1)

@@ -388,6 +388,18 @@ int ed_cohort_select_reference_sets(const int32_t* d_counts, int64_t n_bins, int
                                     int64_t n_bins_reduced, int32_t max_refs, int32_t* n_chosen, int32_t* choice, ed_refset_row* rows,
                                     double* correlations, int32_t* d_ref_out, int64_t* n_selected_bins, void* stream);
 
+/* The same for the tests test_begin <= t < test_end only, every sample of the cohort still a candidate: what ONE RANK of a sample-sharded
+ * cohort runs once it holds all the count columns (reference vignette/vignette.Rnw:390-402 run for its own samples).  Only the rows
+ * [test_begin, test_end) of the correlation matrix are formed (a (test_end - test_begin) x n_samples block of the Gram matrix + its
+ * diagonal), and only the owned tests' prefixes, fits and aggregate references.  The per-test outputs are indexed by t - test_begin:
+ * n_chosen [n_tests], choice [n_tests][K] (columns of the WHOLE cohort), rows [n_tests][K], correlations [n_tests][n_samples],
+ * d_ref_out DEVICE int32 [n_bins][n_tests].  The bin selection uses the row sums over all samples, as the whole-cohort call does:
+ * the shards' results are exactly the corresponding rows / columns of the whole-cohort call's. */
+int ed_cohort_select_reference_sets_range(const int32_t* d_counts, int64_t n_bins, int64_t n_samples, const double* bin_length,
+                                          int64_t n_bins_reduced, int32_t max_refs, int64_t test_begin, int64_t test_end, int32_t* n_chosen,
+                                          int32_t* choice, ed_refset_row* rows, double* correlations, int32_t* d_ref_out,
+                                          int64_t* n_selected_bins, void* stream);
+
 /* ed_cohort_select_reference_sets keeps its device scratch (about 1.5 GB at 10 000 selected bins x 1024 samples) between calls;
  * this returns it to the device. */
 int ed_release_scratch(void);

@@ -110,9 +110,11 @@ static void set_names(SEXP list, const char *const *names, int n)
  *             phi.bins (phi_bins x n_samples: phi.estimates per level; NULL for phi_bins = 1; `phi` is NA then),
  *             complete.bins ((phi_bins + 1) x n_samples: the level edges, :125-126; NULL for phi_bins = 1)) */
 SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, SEXP end, SEXP tprob, SEXP ecl, SEXP phi,
-                        SEXP expected, SEXP prop_tumor, SEXP slab, SEXP want_path, SEXP fit_mode, SEXP phi_bins)
+                        SEXP expected, SEXP prop_tumor, SEXP slab, SEXP want_path, SEXP fit_mode, SEXP phi_bins, SEXP emit_mode)
 {
   const int B = INTEGER(phi_bins)[0];
+  const int em = INTEGER(emit_mode)[0];      /* 0 strict, 1 tables (tiles), 2 tables sample-major (include/exomedepth_amd.h: ed_batch_set_emit_mode) */
+  if (em < 0 || em > 2) Rf_error("emit.mode must be 0 (strict), 1 or 2 (table-driven emissions)");
   const int E = nrows(test), S = ncols(test);
   if (nrows(reference) != E || ncols(reference) != S) Rf_error("test and reference must be integer matrices of the same shape");
   if (XLENGTH(start) != E || XLENGTH(end) != E) Rf_error("start and end must have one element per exon");
@@ -133,6 +135,9 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
   int rc = ed_cohort_create(&co, plan, sl, 2);
   if (rc == ED_OK) rc = ed_cohort_set_option(co, "fit_mode", (double)INTEGER(fit_mode)[0]);
   if (rc == ED_OK && B > 1) rc = ed_cohort_set_option(co, "phi_bins", (double)B);
+  if (rc == ED_OK && B == 1 && em > 0) rc = ed_cohort_set_option(co, "emit_mode", (double)em);
+  /* R's column-major exons x samples matrix IS the sample-major layout emit mode 2 works in: uploaded as it lies, no transposition */
+  if (rc == ED_OK && B == 1 && em == 2) rc = ed_cohort_set_option(co, "counts_layout", 1.0);
   SEXP out = R_NilValue;
   int nprot = 0;
   int64_t n = 0;
@@ -311,7 +316,7 @@ static const R_CallMethodDef CallEntries[] = {                                /*
   {"C_hmm",              (DL_FUNC) &C_hmm,              6},
   {"get_loglike_matrix", (DL_FUNC) &get_loglike_matrix, 5},
   /* cohort-level entries of this library (not in the reference) */
-  {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      14},
+  {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      15},
   {"ed_fit_betabin_batch",    (DL_FUNC) &edr_fit_betabin_batch,    3},
   {"ed_select_reference_set", (DL_FUNC) &edr_select_reference_set, 4},
   {"ed_cohort_reference_sets", (DL_FUNC) &edr_cohort_reference_sets, 4},

@@ -117,3 +117,44 @@ def test_select_reference_set_sharded_merge_world_size_2():
     st = exp["summary.stats"]
     assert np.isnan(st["expected_BF"][19:]).all() and not np.isnan(st["phi"][19]) and np.isnan(st["phi"][20:]).all()
     assert len(exp["reference.choice"]) == int(np.nanargmax(st["expected_BF"])) + 1
+
+
+def _cohort_refsets_worker(rank, world, port, q, S, E):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exomedepth_amd import dist as eddist
+    rng = np.random.default_rng(5)
+    counts = rng.integers(0, 1000, (E, S)).astype(np.int32)       # every rank can rebuild the whole matrix: the check below uses it
+    lo, hi = eddist.shard_bounds(S, rank, world)
+    seen = {}
+
+    def compute_range(all_counts, t0, t1):    # stands where the GPU entry runs: records what it was handed
+        seen["all"] = all_counts.numpy().copy()
+        seen["range"] = (t0, t1)
+        ref = all_counts.sum(dim=1, keepdim=True) - all_counts[:, t0:t1]      # "all the others" as a stand-in aggregate reference
+        return {"reference": ref, "n_chosen": np.full(t1 - t0, S - 1, dtype=np.int32)}
+
+    res = eddist.cohort_reference_sets_sharded(torch.from_numpy(np.ascontiguousarray(counts[:, lo:hi])), S, compute_range=compute_range)
+    ok = np.array_equal(seen["all"], counts) and seen["range"] == (lo, hi) and tuple(res["reference"].shape) == (E, hi - lo)
+    ok = ok and np.array_equal(res["reference"].numpy(), counts.sum(axis=1, keepdims=True) - counts[:, lo:hi])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [12, 13])      # equal shards (one all_gather into the (S, E) buffer) and ragged ones (padded)
+def test_cohort_reference_sets_sharded_gathers_every_column_world_size_2(S):
+    """the reference-set stage of a sample-sharded cohort (vignette/vignette.Rnw:390-402 needs ALL samples as candidates): every rank
+    ends up with the whole (E, S) count matrix, column order intact, and is asked for exactly its own tests"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cohort_refsets_worker, args=(r, 2, port, q, S, 37)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got == [(0, True), (1, True)]

@@ -35,10 +35,13 @@ def test_two_ranks_share_one_gpu_and_gather_their_call_tables(edlib):
     chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
     plan = edlib.Plan(chrom_off, start, end, 1e-4, 50000.0)
     want = 0
+    tests = []
     for rank in (0, 1):
         torch.manual_seed(20250620 + 3 + rank)      # (bench.py seeds the global generator too: the gamma variates draw from it)
         test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=20250620 + 3 + 1000 * rank, mean_depth=100.0)
+        tests.append(test)
         b = edlib.Batch(plan, S)
+        b.set_emit_mode(2)       # (bench.py's default mode; the fit -- and with it the calls -- is the same in every mode to 1e-9)
         dphi = torch.empty(S, dtype=torch.float64, device=dev); dexp = torch.empty(S, dtype=torch.float64, device=dev)
         b.fit(test, ref, dphi, dexp)
         b.run(test, ref, dphi, dexp)
@@ -46,3 +49,13 @@ def test_two_ranks_share_one_gpu_and_gather_their_call_tables(edlib):
         b.close()
     plan.close()
     assert d["n_calls"] == want and want > 0
+    # the workflow leg at N = 2: the reference-set stage sharded by tests (every rank: its own columns against ALL 2 S candidates, one
+    # all_gather of the count slabs) must choose, for rank 0's samples, what ONE call on the whole cohort chooses for them
+    w = d["extra"]["workflow"]
+    assert w is not None and w["ranks"] == 2 and w["n_calls"] > 0
+    whole = torch.cat(tests, dim=1).contiguous()
+    bl = (np.asarray(end) - np.asarray(start)) / 1000.0
+    rs = edlib.cohort_select_reference_sets(whole, bl, 10000, max_refs=32, want_reference=False)
+    ch = rs["choice"][:S]
+    assert w["choice_checksum_rank0"] == int(np.sum((ch.astype(np.int64) + 1) * (np.arange(ch.shape[1], dtype=np.int64) + 1)[None, :]))
+    assert abs(w["references_chosen_mean"] - float(rs["n_chosen"][:S].mean())) < 1e-12

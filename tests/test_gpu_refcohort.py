@@ -127,3 +127,25 @@ def test_config4_geometry_every_sample_against_all_others_500k_x_2048(edlib):
         assert [int(v) for v in res["choice"][t, :res["n_chosen"][t]]] == want
         assert torch.equal(agg[:, t], counts[:, want].sum(dim=1).to(torch.int32))
         del others
+
+
+def test_test_ranges_are_the_rows_of_the_whole_cohort_call(edlib):
+    """ed_cohort_select_reference_sets_range: the tests [t0, t1) against all S candidates -- one rank's share of a sample-sharded cohort
+    (vignette/vignette.Rnw:390-402 for its own samples) -- returns exactly the corresponding rows / columns of the whole-cohort call:
+    choices, summary statistics, correlations, aggregate references"""
+    from exomedepth_amd import synth
+    E, S = 6000, 100
+    chrom_off, start, end = synth.exon_design(E, 4, 31)
+    counts, _, _, _, _ = synth.counts_numpy(chrom_off, S, 31, n_segments=2, mean_depth=80.0)
+    bl = (end - start) / 1000.0
+    whole = edlib.cohort_select_reference_sets(counts, bl, 2000, want_correlations=True)
+    ref_whole = whole["reference"].to_host()
+    for t0, t1 in ((0, 37), (37, 100), (50, 51), (31, 97)):       # block boundaries of the Gram tiles (32) inside and outside
+        part = edlib.cohort_select_reference_sets(counts, bl, 2000, want_correlations=True, test_range=(t0, t1))
+        assert part["n.bins"] == whole["n.bins"]
+        assert np.array_equal(part["n_chosen"], whole["n_chosen"][t0:t1]) and np.array_equal(part["choice"], whole["choice"][t0:t1])
+        assert part["summary.stats"].tobytes() == whole["summary.stats"][t0:t1].tobytes()
+        assert np.array_equal(part["correlations"], whole["correlations"][t0:t1])
+        assert np.array_equal(part["reference"].to_host(), ref_whole[:, t0:t1])
+    with pytest.raises(Exception, match="tests"):
+        edlib.cohort_select_reference_sets(counts, bl, 2000, test_range=(5, 5))
