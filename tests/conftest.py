@@ -27,6 +27,8 @@ def edlib():
     # the same libamdhip64 instead of loading a second copy (two runtimes in one process do not both see
     # the device).  bench.py imports torch first for the same reason.
     try:
+        if os.environ.get("ED_LIB_VARIANT") in ("asan", "tsan"):    # tools/sanitize.sh: torch's HIP start-up does not survive the preloaded runtime
+            raise ImportError
         import torch
         if torch.cuda.is_available():
             torch.cuda.init()
