@@ -327,3 +327,83 @@ def test_cohort_pipeline_in_table_modes(edlib):
         assert np.array_equal(res["path"], res0["path"]) and np.array_equal(res["calls"], res0["calls"])
         co.close(); co0.close()
     plan.close()
+
+
+def test_bundled_data_in_table_modes(edlib, oracle):
+    """BASELINE.json configs[0]: the four samples of the reference's bundled data (tests/golden/exomecount_chr1.npz) at the parameters the
+    reference's arithmetic fits (stored in the fixture), in both table modes: 0 discordant Viterbi states / call rows against the stored
+    result of the libm flavour, log-likelihoods within the tolerance of it"""
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(G, "exomecount_chr1.npz"))
+    exp = np.load(os.path.join(G, "config1_expected.npz"))
+    start, end, counts = d["start"], d["end"], d["counts"].astype(np.int32)
+    n = start.size
+    chrom_off = np.array([0, n], np.int32)
+    test = np.ascontiguousarray(counts[:, :4])
+    ref = np.ascontiguousarray(counts.sum(axis=1, dtype=np.int32)[:, None] - test)
+    phi = np.array([float(exp["phi%d" % i]) for i in range(4)])
+    p = np.array([float(exp["p%d" % i]) for i in range(4)])
+    plan = ed.Plan(chrom_off, start, end)
+    for mode, layout in ((1, 0), (2, 0), (2, 1)):
+        b = ed.Batch(plan, 4)
+        b.set_emit_mode(mode); b.set_counts_layout(layout)
+        b.run(*((np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)) if layout else (test, ref)), phi, p)
+        ll, path, calls = b.loglik(), b.path(), b.calls()
+        for i in range(4):
+            assert b.emit_tables(i)[0] > 0
+            ell, _ = oracle.get_loglike_matrix(phi[i], p[i], test[:, i] + ref[:, i], test[:, i], 1.0, oracle.LIBM)
+            assert close(ll[:, :, i], ell).all()
+            assert np.array_equal(path[:, i].astype(np.int8), exp["path%d" % i]), (mode, layout, i)
+            mine = calls[calls["sample"] == i]
+            got = np.stack([mine["start_exon"] + 1, mine["end_exon"] + 1, mine["type"], mine["nexons"]], axis=1).astype(np.int64)
+            assert np.array_equal(got, exp["calls%d" % i].astype(np.int64)), (mode, layout, i)
+        b.close()
+    plan.close()
+
+
+def _whole_columns_against_libm(oracle, plan, chrom_off, start, end, test, ref, phi, p, path, calls, ll, cols):
+    """per column: (values beyond tolerance, discordant states, discordant call rows) against the checker's libm flavour"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(s):
+        t, r = test[:, s], ref[:, s]
+        ell, _ = oracle.get_loglike_matrix(phi[s], p[s], t + r, t, 1.0, oracle.LIBM)
+        epath, ecalls = oracle.callcnvs(ell, chrom_off, start, end)
+        mine = calls[calls["sample"] == s]
+        got = {tuple(int(v) for v in row) for row in zip(mine["start_exon"] + 1, mine["end_exon"] + 1, mine["type"], mine["nexons"])}
+        want = {tuple(int(v) for v in row[:4]) for row in ecalls}
+        return int(np.sum(~close(ll[:, :, s], ell))), int(np.sum(path[:, s].astype(np.int8) != epath)), len(got ^ want)
+    import os
+    with ThreadPoolExecutor(max(1, min(32, (os.cpu_count() or 2) - 1))) as ex:     # the checker is a C call: the GIL is released
+        return list(ex.map(one, cols))
+
+
+@pytest.mark.parametrize("S,mode,layout", [(64, 2, 1), (64, 1, 0), (1024, 2, 1)])
+def test_whole_columns_of_the_headline_geometries(edlib, oracle, S, mode, layout):
+    """BASELINE.json configs[1] (200 000 x 64, every column) and configs[2] (200 000 x 1024, 64 columns spread over the batch), dispersion
+    fitted on the device, emissions from the tables: log-likelihoods within 1e-10 of the reference's arithmetic and 0 discordant Viterbi
+    states / call rows against it on every one of those 200 000-exon columns"""
+    E, C = 200_000, 24
+    chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
+    test, ref, _, _, _ = synth.counts_numpy(chrom_off, S, 20250627, n_segments=6, mean_depth=100.0)
+    plan = ed.Plan(chrom_off, start, end)
+    b = ed.Batch(plan, S)
+    b.set_emit_mode(mode); b.set_counts_layout(layout)
+    t_in, r_in = (np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)) if layout else (test, ref)
+    dt, dr = ed.DeviceArray(t_in), ed.DeviceArray(r_in)
+    dphi, dexp = ed.DeviceArray(np.zeros(S)), ed.DeviceArray(np.zeros(S))
+    b.fit(dt, dr, dphi, dexp)
+    b.run(dt, dr, dphi, dexp)
+    phi, p = dphi.to_host(), dexp.to_host()
+    assert b.fit_unconverged()[0] == 0
+    n_tab = sum(1 for s in range(S) if b.emit_tables(s)[0] > 0)
+    assert n_tab == S
+    cols = list(range(S)) if S == 64 else [int(v) for v in np.linspace(0, S - 1, 64).round()]
+    path, calls = b.path(), b.calls()
+    ll = b.loglik()
+    res = _whole_columns_against_libm(oracle, plan, chrom_off, start, end, test, ref, np.asarray(phi), np.asarray(p), path, calls, ll, cols)
+    assert sum(r[0] for r in res) == 0, "log-likelihoods beyond the tolerance"
+    assert sum(r[1] for r in res) == 0, "discordant Viterbi states"
+    assert sum(r[2] for r in res) == 0, "discordant call rows"
+    b.close(); plan.close()
