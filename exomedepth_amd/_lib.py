@@ -62,6 +62,8 @@ SYMBOLS = [
     ("ed_batch_fit_subset", C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     ("ed_batch_fit_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     ("ed_batch_fit_bins_form", C.c_int, [_vp]),
+    ("ed_batch_n_samples", C.c_int64, [_vp]),
+    ("ed_batch_fit_bins_n_unconverged", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_batch_run_bins", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     ("ed_batch_phi_linear", C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     ("ed_batch_fit_cov", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),

@@ -300,6 +300,12 @@ class Batch:
         """form the last fit_bins took: 1 = count histograms, 0 = per cell (set_fit_histograms(0), or data beyond the bins)"""
         return int(lib().ed_batch_fit_bins_form(self.handle))
 
+    def fit_bins_unconverged(self):
+        """samples the last depth-binned fit left short of its tolerance (the binned Newton's own flags)"""
+        n = C.c_int64(0)
+        check(lib().ed_batch_fit_bins_n_unconverged(self.handle, C.byref(n)))
+        return n.value
+
     def fit_bins(self, test, ref, phi_bins, phi_bins_out, edges_out, expected_out, stream=None):
         """phi.bins > 1 (reference R/class_definition.R:120-147): per sample the depth levels of the reference
         counts (edges_out: (phi_bins + 1, n_samples) complete.bins), one dispersion per level (phi_bins_out:
@@ -516,6 +522,21 @@ class PinnedArray:
             pass
 
 
+def _host_slab(a, layout):
+    """a host count slab in the memory layout the C entry reads: layout 0 -- rows of consecutive samples, any row pitch (a window of
+    the first columns of a wider matrix stays in place); layout 1 -- dense (n, n_exons).  Anything else (Fortran order, strided
+    columns, negative strides) is copied into that form rather than uploaded as it lies."""
+    a = np.asarray(a)
+    if a.ndim != 2:
+        raise ValueError("a count slab is a 2-d array")
+    if layout == 0:
+        ok = (a.shape[1] <= 1 or a.strides[1] == a.itemsize) and a.strides[0] % a.itemsize == 0 and (a.shape[0] <= 1 or a.strides[0] >= a.shape[1] * a.itemsize)
+        return a if ok or a.size == 0 else np.ascontiguousarray(a)
+    if layout == 1:
+        return a if a.flags.c_contiguous else np.ascontiguousarray(a)
+    raise ValueError("layout is 0 ((n_exons, n) arrays) or 1 ((n, n_exons) arrays = R's column-major matrix)")
+
+
 class Cohort:
     """Slabs of a cohort through the library's pipeline (ed_cohort_*): the loop of reference vignette/vignette.Rnw:390-431
     -- new('ExomeDepth') + CallCNVs() per sample -- for slabs of samples, on streams the library owns.
@@ -581,13 +602,15 @@ class Cohort:
         """one slab from host memory.  layout 0: (n_exons, n) sample-minor arrays (or a window of the first n columns of a wider
         matrix: pass n_samples and row_stride); layout 1: R's column-major n_exons x n matrix, i.e. a C-contiguous (n, n_exons)
         array.  dtype int32 or uint16 (the 16-bit wire format).  numpy arrays or PinnedArray.array views."""
-        test, ref = np.asarray(test), np.asarray(ref)
+        test, ref = _host_slab(test, layout), _host_slab(ref, layout)
         if test.dtype != ref.dtype or test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
             raise ValueError("test and ref must both be int32 or both uint16")
         wire = test.dtype.itemsize
         if n_samples is None:
             n_samples = int(test.shape[1] if layout == 0 else test.shape[0])
         if row_stride is None:
+            if layout == 0 and test.strides[0] != ref.strides[0]:
+                raise ValueError("test and ref windows must share their row stride")
             row_stride = int(test.strides[0] // wire) if layout == 0 else 0
         keep = []
         pp = _device_pointer(phi, np.float64, keep) if phi is not None else None
@@ -601,7 +624,7 @@ class Cohort:
     def submit_host_test(self, test, ref, layout, phi=None, expected=None, mixture=1.0, n_samples=None, row_stride=None):
         """one slab whose TEST counts come from host memory (as submit_host) and whose references are on the device already
         (ref: (n_exons, n) int32 CUDA tensor / DeviceArray -- e.g. a window of cohort_select_reference_sets' aggregate references)"""
-        test = np.asarray(test)
+        test = _host_slab(test, layout)
         if test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
             raise ValueError("test must be int32 or uint16")
         wire = test.dtype.itemsize
@@ -623,8 +646,7 @@ class Cohort:
         """(Batch view, device pointer of phi, device pointer of expected) of a ticket"""
         h, pp, pe = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib().ed_cohort_batch(self.handle, int(ticket), C.byref(h), C.byref(pp), C.byref(pe)))
-        n = C.c_int64(0)
-        b = Batch._view(self.plan, 0, h.value)
+        b = Batch._view(self.plan, int(lib().ed_batch_n_samples(h)), h.value)   # the ticket's own width (a short last slab has its own batch)
         return b, pp.value, pe.value
 
     def results(self, ticket, n_samples, path=False, loglik=False, info=True):

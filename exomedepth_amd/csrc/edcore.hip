@@ -1709,6 +1709,7 @@ struct ed_batch {
   struct FitWork* fitw = nullptr;    // workspace of ed_batch_fit (allocated on first use)
   void* binsw = nullptr;             // workspace of ed_batch_fit_bins' histogram form (BinsWork, edbins_hist.inc)
   int bins_form = 0;                 // form the last ed_batch_fit_bins took (ed_batch_fit_bins_form)
+  int64_t bins_unconverged = 0;      // samples the last depth-binned fit left short of its tolerance (ed_batch_fit_bins_n_unconverged)
   int bins_pieces = 1;               // launches the depth-binned emission kernel is cut into (the cohort pipeline sets it)
   int64_t calls_cap = 0;
   hipStream_t stream = nullptr;         // where the results of the last run become available: the caller's stream, or `fin`
@@ -2661,10 +2662,16 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         const double* ctab = nullptr;
         if (bins > 0 && !em.cov) {
           // depth-binned dispersion: the constants lbeta(a1, a2) per (sample, state, reference count) first, then three tasks per cell
-          if (!b->d_ctab) {
+          if (!b->d_ctab || !b->d_left_out) {   // both or neither: a half-made pair must not pass for a made one on the next call
+            if (b->d_ctab) { (void)hipFree(b->d_ctab); b->d_ctab = nullptr; }
+            if (b->d_left_out) { (void)hipFree(b->d_left_out); b->d_left_out = nullptr; }
             if (hipMalloc((void**)&b->d_ctab, (size_t)3 * kBinsRtab * S * 8) != hipSuccess ||
-                hipMalloc((void**)&b->d_left_out, (size_t)egrid.x * egrid.y * egrid.z) != hipSuccess)
+                hipMalloc((void**)&b->d_left_out, (size_t)egrid.x * egrid.y * egrid.z) != hipSuccess) {
+              if (b->d_ctab) { (void)hipFree(b->d_ctab); b->d_ctab = nullptr; }
+              b->d_left_out = nullptr;
+              (void)hipGetLastError();
               return ed_fail(ED_ERR_NOMEM, "ed_batch_run_bins: cannot allocate the table of constants");
+            }
           }
           hipLaunchKernelGGL(k_bins_ctab, dim3((unsigned)((S + 63) / 64), (unsigned)(kBinsRtab / 4)), dim3(256), 0, st, bins, d_edges, d_phi, d_expected,
                              mixture, S, kBinsRtab, b->d_ctab, em.skip);
@@ -2977,6 +2984,7 @@ ED_EXPORT int ed_batch_fit_n_unconverged(ed_batch* b, int64_t* n_unconverged, in
   return ED_OK;
 }
 
+ED_EXPORT int64_t ed_batch_n_samples(const ed_batch* b) { return b ? b->S : 0; }
 ED_EXPORT const double* ed_batch_loglik(const ed_batch* b)
 {
   if (!b || !(b->keep_loglik || !b->fused)) return nullptr;

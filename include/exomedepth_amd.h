@@ -128,6 +128,8 @@ int64_t ed_plan_n_exons(const ed_plan* plan);
  *   Viterbi path     uint8  [n_exons][n_samples]     (0 normal, 1 deletion, 2 duplication)
  *   call table       ed_call[n_calls], ordered by (sample, chromosome, position) */
 int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples);
+/* the n_samples the batch was made for (0 for NULL) -- e.g. of a cohort ticket's batch (ed_cohort_batch), which is the slab's width */
+int64_t ed_batch_n_samples(const ed_batch* batch);
 void ed_batch_destroy(ed_batch* batch);
 
 /* Fit the per-sample beta-binomial model  cbind(test, reference) ~ 1  (what aod::betabin does at
@@ -171,6 +173,10 @@ int ed_batch_fit_bins(ed_batch* batch, const int32_t* d_test, const int32_t* d_r
  * (what ed_batch_set_fit_histograms(batch, 0) asks for, and what data beyond the bins -- a 0.85 quantile of the reference counts
  * >= 8192, > 32768 cells of a sample outside its level's bins -- fall back to).  Same estimate to the fit's tolerance. */
 int ed_batch_fit_bins_form(const ed_batch* batch);
+/* Samples the last depth-binned fit (ed_batch_fit_bins, or the cohort pipeline's fit of this batch's slab once its ticket has been
+ * waited for) left short of its tolerance after the 40-pass budget -- the depth-binned Newton's own flags, not those of the
+ * single-dispersion fit it starts from (ed_batch_fit_n_unconverged).  ed_cohort_run_status reports their sum in phi_bins mode. */
+int ed_batch_fit_bins_n_unconverged(const ed_batch* batch, int64_t* n);
 /* ed_batch_run with the per-exon dispersion phi.linear = approxfun(bin mid-points, phi.estimates)(reference)
  * (:141-147) evaluated on the fly; everything downstream of the emissions is ed_batch_run's.  Not available in
  * fused mode. */

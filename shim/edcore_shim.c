@@ -93,6 +93,19 @@ static void set_names(SEXP list, const char *const *names, int n)
   UNPROTECT(1);
 }
 
+/* device objects of one .Call, owned by an external pointer (released by the call itself on every return path, by its finalizer if
+ * an R error unwound the call) */
+typedef struct { ed_plan *plan; ed_cohort *co; } edr_guard;
+static void edr_guard_release(SEXP p)
+{
+  edr_guard *g = (edr_guard *) R_ExternalPtrAddr(p);
+  if (!g) return;
+  if (g->co) ed_cohort_destroy(g->co);
+  if (g->plan) ed_plan_destroy(g->plan);
+  free(g);
+  R_ClearExternalPtr(p);
+}
+
 /* CallCNVs for a cohort: per sample what new('ExomeDepth') (R/class_definition.R:82-191: aod::betabin, get_loglike_matrix) and
  * CallCNVs() (:311-419: C_hmm per chromosome, call decoration :379-405) produce.
  *   test, reference   integer matrices n_exons x n_samples; exons ordered as CallCNVs orders them (:323-336)
@@ -126,20 +139,29 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
   if (B > 1 && given) Rf_error("with phi.bins > 1 the dispersions are fitted per depth level: phi and expected cannot be given");
   const double mix = REAL(prop_tumor)[0];
   if (mix != 1) Rprintf("As a warning (this could be normal), the mixture coefficient is %f\n", mix);   /* src/CNV_estimate.cpp:61 */
-  ed_plan *plan = NULL;
-  ed_cohort *co = NULL;
-  if (ed_plan_create(&plan, 0, E, C, INTEGER(chrom_off), INTEGER(start), INTEGER(end), REAL(tprob)[0], REAL(ecl)[0]) != ED_OK)
+  /* the plan and the cohort live in an external pointer with a finalizer from before the first R allocation on: an R error raised
+   * inside an allocation below (a longjmp out of this function) leaves them to the garbage collector instead of leaking device memory */
+  int nprot = 0;
+  SEXP guard = PROTECT(R_MakeExternalPtr(NULL, R_NilValue, R_NilValue)); nprot++;
+  edr_guard *gd = (edr_guard *) calloc(1, sizeof(edr_guard));
+  if (!gd) Rf_error("exomedepth_amd: out of memory");
+  R_SetExternalPtrAddr(guard, gd);
+  R_RegisterCFinalizerEx(guard, edr_guard_release, TRUE);
+  if (ed_plan_create(&gd->plan, 0, E, C, INTEGER(chrom_off), INTEGER(start), INTEGER(end), REAL(tprob)[0], REAL(ecl)[0]) != ED_OK) {
+    edr_guard_release(guard);
     Rf_error("exomedepth_amd: %s", ed_last_error());
+  }
+  ed_plan *plan = gd->plan;
   int sl = INTEGER(slab)[0];
   if (sl <= 0 || sl > S) sl = S;
-  int rc = ed_cohort_create(&co, plan, sl, 2);
+  int rc = ed_cohort_create(&gd->co, plan, sl, 2);
+  ed_cohort *co = gd->co;
   if (rc == ED_OK) rc = ed_cohort_set_option(co, "fit_mode", (double)INTEGER(fit_mode)[0]);
   if (rc == ED_OK && B > 1) rc = ed_cohort_set_option(co, "phi_bins", (double)B);
   if (rc == ED_OK && B == 1 && em > 0) rc = ed_cohort_set_option(co, "emit_mode", (double)em);
   /* R's column-major exons x samples matrix IS the sample-major layout emit mode 2 works in: uploaded as it lies, no transposition */
   if (rc == ED_OK && B == 1 && em == 2) rc = ed_cohort_set_option(co, "counts_layout", 1.0);
   SEXP out = R_NilValue;
-  int nprot = 0;
   int64_t n = 0;
   if (rc == ED_OK) {
     SEXP rphi = PROTECT(allocVector(REALSXP, S)); nprot++;
@@ -201,8 +223,7 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
       }
     }
   }
-  if (co) ed_cohort_destroy(co);
-  ed_plan_destroy(plan);
+  edr_guard_release(guard);
   UNPROTECT(nprot);
   if (rc != ED_OK) Rf_error("exomedepth_amd: %s", ed_last_error());
   return out;

@@ -23,6 +23,7 @@ typedef enum { FALSE = 0, TRUE } Rboolean;
 #define REALSXP 14
 #define STRSXP 16
 #define VECSXP 19
+#define EXTPTRSXP 22
 #define RAWSXP 24
 #define NA_INTEGER R_NaInt
 #define NA_REAL R_NaReal
@@ -55,6 +56,12 @@ SEXP Rf_getAttrib(SEXP x, SEXP name);
 void Rprintf(const char *fmt, ...);
 void Rf_error(const char *fmt, ...) __attribute__((noreturn));
 char *R_alloc(size_t n, int size);
+typedef void (*R_CFinalizer_t)(SEXP);
+SEXP R_MakeExternalPtr(void *p, SEXP tag, SEXP prot);
+void *R_ExternalPtrAddr(SEXP s);
+void R_SetExternalPtrAddr(SEXP s, void *p);
+void R_ClearExternalPtr(SEXP s);
+void R_RegisterCFinalizerEx(SEXP s, R_CFinalizer_t fun, Rboolean onexit);
 
 #define allocVector Rf_allocVector
 #define allocMatrix Rf_allocMatrix

@@ -39,8 +39,13 @@ double *REAL(SEXP x) { return (double *)x->data; }
 int *INTEGER(SEXP x) { return (int *)x->data; }
 R_xlen_t XLENGTH(SEXP x) { return x->n; }
 int LENGTH(SEXP x) { return (int)x->n; }
+static int g_alloc_countdown = -1;   /* minir_fail_alloc_after(k): the k-th allocation from now raises an R error (allocation failure) */
+static SEXP g_fin_obj[64];
+static R_CFinalizer_t g_fin_fun[64];
+static int g_fin_n = 0;
 SEXP Rf_allocVector(SEXPTYPE type, R_xlen_t length)
 {
+  if (g_alloc_countdown > 0 && --g_alloc_countdown == 0) { g_alloc_countdown = -1; Rf_error("cannot allocate vector of size %ld", (long)length); }
   SEXP s = (SEXP)calloc(1, sizeof *s);
   const size_t el = type == REALSXP ? 8 : (type == INTSXP ? 4 : ((type == RAWSXP || type == CHARSXP) ? 1 : sizeof(SEXP)));
   s->type = type; s->n = length; s->nrow = (int)length; s->ncol = 1;
@@ -89,6 +94,27 @@ void Rf_error(const char *fmt, ...)
   fprintf(stderr, "mini_r: Rf_error outside a call: %s\n", g_err);
   abort();
 }
+SEXP R_MakeExternalPtr(void *p, SEXP tag, SEXP prot)
+{
+  (void)tag; (void)prot;
+  SEXP s = Rf_allocVector(EXTPTRSXP, 0);
+  free(s->data);
+  s->data = p;
+  return s;
+}
+void *R_ExternalPtrAddr(SEXP s) { return s->data; }
+void R_SetExternalPtrAddr(SEXP s, void *p) { s->data = p; }
+void R_ClearExternalPtr(SEXP s) { s->data = NULL; }
+void R_RegisterCFinalizerEx(SEXP s, R_CFinalizer_t fun, Rboolean onexit)
+{
+  (void)onexit;
+  if (g_fin_n == 64) {   /* forget the pointers that have been cleared already */
+    int k = 0;
+    for (int i = 0; i < g_fin_n; i++) if (g_fin_obj[i]->data) { g_fin_obj[k] = g_fin_obj[i]; g_fin_fun[k] = g_fin_fun[i]; k++; }
+    g_fin_n = k;
+  }
+  if (g_fin_n < 64) { g_fin_obj[g_fin_n] = s; g_fin_fun[g_fin_n] = fun; g_fin_n++; }
+}
 char *R_alloc(size_t n, int size) { return (char *)calloc(n ? n : 1, (size_t)size); }   /* (leaks: a test process) */
 
 int R_registerRoutines(DllInfo *info, const R_CMethodDef *const c, const R_CallMethodDef *const call,
@@ -108,6 +134,19 @@ int R_registerRoutines(DllInfo *info, const R_CMethodDef *const c, const R_CallM
 Rboolean R_useDynamicSymbols(DllInfo *info, Rboolean value) { (void)info; g_dyn = (int)value; return TRUE; }
 
 /* ---- what the test drives ---- */
+void minir_fail_alloc_after(int k) { g_alloc_countdown = k; }
+/* what a garbage collection does to unreachable external pointers: every registered finalizer runs once; returns how many found
+ * their pointer still set (objects a longjmp left behind) */
+int minir_run_finalizers(void)
+{
+  int live = 0;
+  for (int i = 0; i < g_fin_n; i++) {
+    if (g_fin_obj[i]->data) live++;
+    g_fin_fun[i](g_fin_obj[i]);
+  }
+  g_fin_n = 0;
+  return live;
+}
 int minir_n_registered(void) { return g_reg_n; }
 const char *minir_registered_name(int i) { return g_reg_names[i]; }
 int minir_registered_nargs(int i) { return g_reg_nargs[i]; }

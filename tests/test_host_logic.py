@@ -1,6 +1,7 @@
 """Host-side logic of the interface mirror (no GPU): exon ordering of CallCNVs, R-style coercions,
 synthetic generators, sample sharding."""
 import numpy as np
+import pytest
 
 import exomedepth_amd as ed
 from exomedepth_amd import api, dist, synth
@@ -118,3 +119,23 @@ def test_bin_thinning_follows_r_seq_semantics():
     from oracle import refset_oracle
     for length, nred in ((50, 24), (9000, 700), (123457, 10000)):
         assert np.array_equal(refset_oracle.r_seq_thin(length, nred), lib_positions(length, nred))
+
+
+def test_host_slabs_are_checked_before_they_are_uploaded():
+    """Cohort.submit_host reads raw memory: arrays that are not in the layout the C entry walks are copied into it, windows of wider
+    matrices stay in place (exomedepth_amd/api.py:_host_slab)"""
+    from exomedepth_amd.api import _host_slab
+    wide = np.arange(60, dtype=np.int32).reshape(6, 10)
+    win = wide[:, :4]                                    # first columns of a wider matrix: in place, row pitch 10
+    assert _host_slab(win, 0) is win and win.strides[0] == 40
+    f = np.asfortranarray(wide)
+    g = _host_slab(f, 0)
+    assert g is not f and g.flags.c_contiguous and np.array_equal(g, wide)
+    assert _host_slab(wide[:, ::2], 0).flags.c_contiguous and _host_slab(wide[::-1], 0).strides[0] > 0
+    t = wide.T                                           # (n, n_exons) view of R's matrix: dense only after a copy
+    assert _host_slab(np.ascontiguousarray(t), 1).flags.c_contiguous and _host_slab(t, 1).flags.c_contiguous
+    assert np.array_equal(_host_slab(t, 1), t)
+    with pytest.raises(ValueError):
+        _host_slab(wide, 2)
+    with pytest.raises(ValueError):
+        _host_slab(np.zeros(5, np.int32), 0)

@@ -63,6 +63,7 @@ def shim():
                             ("minir_call5", vp, [vp] * 6), ("minir_call6", vp, [vp] * 7), ("minir_callv", vp, [vp, C.c_int, C.POINTER(vp)]),
                             ("minir_int_matrix", vp, [vp, C.c_int, C.c_int]), ("minir_nil", vp, []), ("minir_name", C.c_char_p, [vp, C.c_int]),
                             ("minir_raw", C.POINTER(C.c_ubyte), [vp]), ("minir_int_data", C.POINTER(C.c_int), [vp]),
+                            ("minir_fail_alloc_after", None, [C.c_int]), ("minir_run_finalizers", C.c_int, []),
                             ("REAL", C.POINTER(C.c_double), [vp]), ("XLENGTH", C.c_ssize_t, [vp]), ("VECTOR_ELT", vp, [vp, C.c_ssize_t])):
         fn = getattr(R, name)
         fn.restype, fn.argtypes = res, args
@@ -304,6 +305,30 @@ def test_call_cnvs_batch_through_sexp_equals_ctypes_path(shim, edlib, given, sla
     assert got["n.unconverged"][0] == 0 and got["n.gsl.errors"][0] == 0
     assert shim.R.minir_protect_balance() == 0
     b.close(); plan.close()
+
+
+@pytest.mark.gpu
+def test_call_cnvs_batch_leaves_nothing_behind_when_r_unwinds(shim, edlib):
+    """an R error inside one of the entry's allocations (allocation failure: a longjmp out of the .Call) leaves the plan and the cohort
+    to their external pointer's finalizer -- nothing leaks; the entries that return normally have released theirs already"""
+    chrom_off, start, end, test, ref, p, phi = _cohort_case(E=3000, S=40)
+    args = lambda: (shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start), shim.integer(end), shim.real([1e-4]),
+                    shim.real([50000.0]), shim.nil, shim.nil, shim.real([1.0]), shim.integer([40]), shim.integer([1]), shim.integer([0]),
+                    shim.integer([1]), shim.integer([0]))
+    shim.R.minir_run_finalizers()
+    res, out, err = shim.dot_call("ed_call_cnvs_batch", *args())
+    assert res is not None and err == ""
+    assert shim.R.minir_run_finalizers() == 0                     # a normal return: released by the call itself
+    for k in (2, 3, 4, 5, 8):                                     # the k-th allocation of the call fails (1 is the guard itself: nothing made yet)
+        a = args()
+        shim.R.minir_fail_alloc_after(k)
+        res, out, err = shim.dot_call("ed_call_cnvs_batch", *a)
+        shim.R.minir_fail_alloc_after(-1)
+        assert res is None and "cannot allocate" in err
+        assert shim.R.minir_run_finalizers() == 1                 # the collector's turn: the objects the unwinding left behind
+        assert shim.R.minir_run_finalizers() == 0
+    res, out, err = shim.dot_call("ed_call_cnvs_batch", *args())  # and the library is as it was
+    assert res is not None and err == ""
 
 
 @pytest.mark.gpu
