@@ -49,8 +49,8 @@ def matching_profile():
 
 def pmc_figures(meta, kernel, cells_per_step, kernel_cells_per_s):
     """HBM traffic per launch and VALU figures of `kernel` from the PMC passes of profile `meta` (same build, see
-    matching_profile): FETCH_SIZE x2 (gfx950 tallies the 128-byte requests of a coalesced stream at 64 B,
-    MI355X_MICROARCH.md) + WRITE_SIZE, KB -> bytes; SQ_INSTS_VALU x 64 lanes / cells; SQ_ACTIVE_INST_VALU x 4 /
+    matching_profile): FETCH_SIZE x2 (gfx950 tallies the 128-byte requests of a coalesced 16-byte-per-lane stream at 64 B,
+    MI355X_MICROARCH.md; x1 for k_emit_tab_sm's 4-byte-per-lane reads, calibrated on its known count bytes) + WRITE_SIZE, KB -> bytes; SQ_INSTS_VALU x 64 lanes / cells; SQ_ACTIVE_INST_VALU x 4 /
     (GRBM_GUI_ACTIVE / 8 XCDs) / 1024 SIMDs.  valu_frac_of_fp64_peak combines the profile's instruction count per cell
     with THIS run's live kernel rate."""
     import csv
@@ -70,8 +70,13 @@ def pmc_figures(meta, kernel, cells_per_step, kernel_cells_per_s):
     if (kernel, "FETCH_SIZE") in fe and (kernel, "WRITE_SIZE") in wr:
         f, n = fe[(kernel, "FETCH_SIZE")]
         w = wr[(kernel, "WRITE_SIZE")][0]
-        out["traffic_bytes_per_launch"] = (2.0 * f + w) * 1024.0
-        out["traffic_bytes_per_step"] = (2.0 * f + w) * 1024.0 * n / runs(fe, "FETCH_SIZE")
+        # the guide's x2 is for 16-byte-per-lane streams; "other access widths are uncalibrated: calibrate on a known byte count".
+        # k_emit_tab_sm reads its counts 4 bytes per lane: a known 8 B/cell = 1.64 GB per 200 000 x 1024 launch, against which the raw
+        # counter reads 1.62-1.66 GB (profiles/r04_a, r04_b) -- factor 1 for that kernel.
+        ff = 1.0 if kernel == "k_emit_tab_sm" else 2.0
+        out["fetch_size_factor"] = ff
+        out["traffic_bytes_per_launch"] = (ff * f + w) * 1024.0
+        out["traffic_bytes_per_step"] = (ff * f + w) * 1024.0 * n / runs(fe, "FETCH_SIZE")
         out["launches_per_step_profiled"] = n / runs(fe, "FETCH_SIZE")
     if (kernel, "SQ_INSTS_VALU") in sq and (kernel, "GRBM_GUI_ACTIVE") in gr:
         insts, n = sq[(kernel, "SQ_INSTS_VALU")]
@@ -814,6 +819,8 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * E * S / n_launch,
                          "kernel_cells_per_s": kernel_cells_per_s,
                          "algorithmic_bytes_per_cell_with_likelihood_matrix": 33,
+                         "frac_with_likelihood_matrix": (33 * E * S / t_emit / 1e9 / HBM_PEAK_GBS) if t_emit > 0 else None,
+                         "frac_alone_with_likelihood_matrix": (33 * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "kernel_ms_alone": alone_ms,
                          "frac_alone": (ALGO_BYTES_PER_CELL * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "valu": pmc if pmc else why_not,

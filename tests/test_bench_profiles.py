@@ -22,11 +22,17 @@ def test_stale_profiles_are_refused_and_matching_ones_parse(tmp_path, monkeypatc
         pytest.skip("no committed profile matches the kernel sources (%s): bench.py withholds traffic / valu until "
                     "tools/profile_round.sh is run again" % here)
     assert meta["csrc_sha16"] == here
-    fig = bench.pmc_figures(meta, "k_emit_batch", 200_000.0 * 1024, 2.27e10)
+    kernel = meta.get("workload", {}).get("kernel", "k_emit_batch")         # the emission kernel of the mode the profile was taken in
+    fig = bench.pmc_figures(meta, kernel, 200_000.0 * 1024, 2.27e10 if kernel == "k_emit_batch" else 1.1e11)
     assert fig["profile"] == meta["tag"]
     assert 5e9 < fig["traffic_bytes_per_step"] < 3e10                       # 33 B/cell materialised + table gathers
-    assert 1000 < fig["valu_lane_instructions_per_cell"] < 1600
-    assert 0.5 < fig["valu_busy"] <= 1.0 and 0.3 < fig["valu_frac_of_fp64_peak"] < 1.0
+    if kernel == "k_emit_batch":                                            # strict mode: GSL's arithmetic, VALU-bound
+        assert 1000 < fig["valu_lane_instructions_per_cell"] < 1600
+        assert 0.5 < fig["valu_busy"] <= 1.0 and 0.3 < fig["valu_frac_of_fp64_peak"] < 1.0
+    else:                                                                   # table-driven modes: a memory-streaming kernel
+        assert 60 < fig["valu_lane_instructions_per_cell"] < 400 and fig["valu_busy"] < 0.9
+        if kernel == "k_emit_tab_sm":
+            assert fig["fetch_size_factor"] == 1.0 and fig["traffic_bytes_per_step"] < 8e9
     # a profile stamped with another fingerprint is not used
     fake = tmp_path / "profiles"
     fake.mkdir()

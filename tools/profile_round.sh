@@ -30,6 +30,38 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LD
   python tools/pmc_summary.py $OUT/pmc_${N}_counter_collection.csv > $OUT/pmc_$N.csv
   rm -f $OUT/pmc_${N}_counter_collection.csv $OUT/pmc_${N}_kernel_trace.csv
 done
+# ---- the workflow leg (extra.workflow: upload -> reference sets for every sample -> calls): its kernels (k_rc_*, k_fit_accum_batched, ...)
+#      in a kernel trace of their own and one PMC pass (MFMA work of k_rc_gram) ----
+WF="--steps 1 --warmup 0 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --strict-steps 0 --workflow-reps 2"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o wf -- python bench.py $WF $EXTRA > $OUT/bench_wf.log 2>&1
+grep -h '^{' $OUT/bench_wf.log > $OUT/bench_line_wf.json
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT -o pmc_WF -- python bench.py $WF $EXTRA > $OUT/pmc_WF.log 2>&1
+python tools/pmc_summary.py $OUT/pmc_WF_counter_collection.csv > $OUT/pmc_WF.csv
+rm -f $OUT/pmc_WF_counter_collection.csv $OUT/pmc_WF_kernel_trace.csv
+python - "$OUT" <<'PY'
+import csv, json, sys
+out = sys.argv[1]
+rows = list(csv.reader(open(out + "/wf_kernel_stats.csv")))
+keep = [r for r in rows[1:] if "(anonymous namespace)::k_" in r[0] or "(anonymous namespace)::hg" in r[0]]
+with open(out + "/wf_kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f); w.writerow(rows[0]); w.writerows(keep)
+# k_rc_gram: 2 * n4 * 32 * 32 flop per (block pair of the lower triangle incl. the diagonal, all slices together)
+h = {k: i for i, k in enumerate(rows[0])}
+line = json.load(open(out + "/bench_line_wf.json"))
+wf = line["extra"]["workflow"]
+S = int(line["config"]["samples_per_gpu"]); n = int(wf.get("n_bins_selected", wf.get("n_bins_reduced", 10000)))
+Sp, n4 = (S + 31) // 32 * 32, (n + 3) // 4 * 4
+nb = Sp // 32
+flop = 2.0 * n4 * 1024 * (nb * (nb + 1) // 2)
+for r in keep:
+    if "k_rc_gram(" in r[0]:
+        avg_ns = float(r[h["AverageNs"]])
+        json.dump({"kernel": "k_rc_gram", "flop_per_launch": flop, "avg_ms": avg_ns / 1e6, "achieved_tflops_f64": flop / avg_ns / 1e3,
+                   "peak_tflops_f64_matrix": 78.6, "frac": flop / avg_ns / 1e3 / 78.6, "n_rows": n4, "S_padded": Sp,
+                   "note": "lower triangle of 32x32 blocks incl. the diagonal, v_mfma_f64_16x16x4_f64; peak = MI355X FP64 matrix 78.6 TF/s (MI355X_MICROARCH.md)"},
+                  open(out + "/rc_gram.json", "w"), indent=1)
+PY
+rm -f $OUT/wf_kernel_trace.csv $OUT/wf_domain_stats.csv
 python - "$OUT" "$TAG" $EXTRA <<'PY'
 import json, sys, time
 sys.path.insert(0, ".")
