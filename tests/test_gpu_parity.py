@@ -434,8 +434,10 @@ def test_argument_errors_are_reported_not_crashed(edlib):
     plan = edlib.Plan(chrom_off, start, end)
     with pytest.raises(edlib.EdError):
         edlib.Batch(plan, 0)
-    with pytest.raises(edlib.EdError, match="65536"):
+    with pytest.raises(edlib.EdError, match="32768"):
         edlib.Batch(plan, 600_000)
+    with pytest.raises(edlib.EdError, match="32768"):
+        edlib.Batch(plan, 32_769)
     batch = edlib.Batch(plan, 3)
     with pytest.raises(edlib.EdError, match="no ed_batch_run"):
         batch.calls()
@@ -538,4 +540,30 @@ def test_get_loglike_matrix_with_phi_above_one_matches_the_checker(edlib, oracle
         assert np.all((g.view(np.int64) == np.ascontiguousarray(w).view(np.int64)) | (np.isnan(g) & np.isnan(w))), s
     assert nerr_b == tot_err and tot_err > 0
     assert b.verify_emissions(tt, rr, phs, es)[1] == 0
+    b.close(); plan.close()
+
+
+def test_widest_batch_reads_its_tables_in_range(edlib):
+    """the widest batch ed_batch_create accepts (32 768 samples): the per-sample tables of the strict kernel are read through a buffer
+    resource of 2^31 - 1 bytes, 49 152 bytes per sample -- every state of every sample must lie inside it (a wider batch would read zeros
+    for the samples beyond byte 2^31: the cap).  Every cell against the device's per-cell evaluation, first and last samples against the
+    checker."""
+    from exomedepth_amd import synth
+    S, E = 32_768, 96
+    chrom_off, start, end = synth.exon_design(E, 2, 5)
+    rng = np.random.default_rng(5)
+    test = rng.poisson(60.0, size=(E, S)).astype(np.int32)
+    ref = rng.poisson(400.0, size=(E, S)).astype(np.int32)
+    phi = rng.uniform(0.003, 0.05, S); p = rng.uniform(0.1, 0.2, S)
+    plan = edlib.Plan(chrom_off, start, end)
+    b = edlib.Batch(plan, S)
+    dt, dr, dphi, dp = edlib.DeviceArray(test), edlib.DeviceArray(ref), edlib.DeviceArray(phi), edlib.DeviceArray(p)
+    b.run(dt, dr, dphi, dp)
+    ncmp, nbad, first = b.verify_emissions(dt, dr, dphi, dp)
+    assert ncmp == 3 * E * S and nbad == 0, first
+    ll = b.loglik()
+    from oracle import edoracle as eo
+    for s in (0, 1, S // 2, 43_690 * 3 // 4, S - 2, S - 1):
+        ell, _ = eo.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, eo.PORTABLE)
+        assert np.array_equal(bits(ll[:, :, s]), bits(ell)), s
     b.close(); plan.close()
