@@ -2895,7 +2895,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnm, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y,     \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 2000 /* optim(control = list(maxit = 2000)) */, d_test, d_ref, cell_rs,  \
-                         E, w.depth, launched, w.fevals, cell_cs, d_phi, d_expected);
+                         E, w.depth, launched, w.fevals, cell_cs, d_phi, d_expected, sm ? 1 : 0);
     if (fit_mode == 1) {
       ED_FIT_NM(hg8, w.cap8) ED_FIT_NM(hg4, w.cap4) ED_FIT_NM(hg2, w.cap2)
       HIP_TRY(hipGetLastError());
@@ -2906,7 +2906,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */, \
-                         d_test, d_ref, cell_rs, E, w.depth, launched, cell_cs, d_phi, d_expected);
+                         d_test, d_ref, cell_rs, E, w.depth, launched, cell_cs, d_phi, d_expected, sm ? 1 : 0);
     ED_FIT_NEWTON(hg8, w.cap8) ED_FIT_NEWTON(hg4, w.cap4) ED_FIT_NEWTON(hg2, w.cap2)
 #undef ED_FIT_NEWTON
     HIP_TRY(hipGetLastError());
