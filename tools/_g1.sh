@@ -1,12 +1,4 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_tables.py -x -q 2>&1 | tail -5
-Q="--steps 12 --warmup 3 --cpu-samples 0 --verify-columns 4 --fit-concordance 0 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --config1-steps 0"
-for rep in 1 2; do
-for V in 1 0; do
-  ED_SM4=$V timeout 200 python bench.py $Q 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); print('sm4=$V step', round(d['ms_per_step'],3), 'emit live', round(d['roofline']['kernel_ms_per_step'],3), 'alone', round(d['roofline']['kernel_ms_alone'],3), {k: d['verify'][k] for k in ('loglik_beyond_1e-10','discordant_states','discordant_calls')})"
-done
-done
+timeout 300 python tools/_g3.py 2>&1 | grep "7 max\|oracle" | head -6
+timeout 900 python -m pytest tests/test_gpu_fit.py tests/test_gpu_fit_concordance.py tests/test_gpu_refcohort.py tests/test_gpu_refset.py tests/test_gpu_config1.py -x -q 2>&1 | tail -3
+timeout 600 python tools/fuzz_fit_sm.py 150 2>&1 | tail -4
