@@ -69,6 +69,7 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             # timing experiments on k_emit_tab_sm (wrong results by construction): without its stores / LDS look-ups / global look-ups
             "xnostore": ["-DED_SM_X_NOSTORE"], "xnolds": ["-DED_SM_X_NOLDS"], "xnoglobal": ["-DED_SM_X_NOGLOBAL"],
             "xnoldsglobal": ["-DED_SM_X_NOLDS", "-DED_SM_X_NOGLOBAL"],
+            "tabper8": ["-DED_TAB_PER=8"],
             # round 1's Horner step (coefficient as an "s" asm operand): contains the VALU-write-SGPR -> VALU-read hazard
             # (tools/isa_hazard_scan.py); built only to demonstrate it on hardware next to the fixed library
             "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"],

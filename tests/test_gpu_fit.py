@@ -186,3 +186,60 @@ def test_fit_counts_beyond_the_histogram_range(edlib, oracle):
     kernel sums those samples cell by cell (same launch).  A moderately deep case uses bins and overflow lists together."""
     _fit_case(edlib, oracle, E=3000, S=6, seed=45, mean_depth=3000.0)
     _fit_case(edlib, oracle, E=5000, S=5, seed=46, mean_depth=400.0)
+
+
+def _fit_both_layouts(edlib, test, ref, by=1):
+    """(phi, expected, unconverged) from [exons][samples] counts and from sample-major counts"""
+    E, S = test.shape
+    plan = edlib.Plan(np.array([0, E], np.int32), np.arange(E, dtype=np.int32) * 100, np.arange(E, dtype=np.int32) * 100 + 50)
+    out = []
+    for layout in (0, 1):
+        b = edlib.Batch(plan, S)
+        if layout:
+            b.set_emit_mode(2); b.set_counts_layout(1)
+        t, r = (np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)) if layout else (test, ref)
+        dphi, dexp = edlib.DeviceArray(np.zeros(S)), edlib.DeviceArray(np.zeros(S))
+        b.fit(edlib.DeviceArray(t), edlib.DeviceArray(r), dphi, dexp, by=by)
+        out.append((dphi.to_host(), dexp.to_host(), b.fit_unconverged()[0]))
+        b.close()
+    plan.close()
+    return out
+
+
+def test_column_pinned_at_the_dispersion_floor_still_converges_its_mean(edlib, oracle):
+    """nearly binomial columns (the likelihood's maximum lies below the phi >= 1e-6 the fit allows): phi is pinned at the bound and
+    the expected proportion is the maximum GIVEN that phi -- in both layouts, to the fit's tolerance of the checker's"""
+    rng = np.random.default_rng(12)
+    E, S = 300, 24
+    n = rng.integers(150, 600, size=(E, S))
+    p = rng.uniform(0.05, 0.2, S)
+    test = rng.binomial(n, p[None, :]).astype(np.int32)          # no over-dispersion at all
+    ref = (n - test).astype(np.int32)
+    got = _fit_both_layouts(edlib, test, ref)
+    for phi, exp, unconv in got:
+        assert unconv <= 2            # (a maximum just above the bound -- phi ~ 1.4e-6 here -- sits where the psi-gradient is rounding noise: its steps never fall below the tolerance)
+        pinned = phi <= 1.0000002e-6
+        assert pinned.sum() >= S // 3
+        for s in np.flatnonzero(pinned):
+            # at phi = 1e-6 the model is the binomial to ~1e-4 relative in the likelihood's curvature: its maximum in p is sum(y) / sum(n) to ~1e-6
+            want = test[:, s].sum() / n[:, s].sum()
+            assert abs(exp[s] - want) / want < 2e-5, (s, exp[s], want)
+    both = (got[0][0] <= 1.0000002e-6) & (got[1][0] <= 1.0000002e-6)
+    assert np.max(np.abs(got[0][1][both] - got[1][1][both]) / got[0][1][both]) < 1e-8
+
+
+def test_sample_major_histograms_with_bins_that_leave_the_lds_early(edlib, oracle):
+    """columns of 120 000 exons on three count values: a bin passes 16 384 cells inside a chunk and is carried out of the 16-bit LDS bins
+    (k_fit_hist_sm); second-level ranges and lists in play (reference counts beyond 4 096); the estimate equals the [E][S] form's and the
+    checker's"""
+    rng = np.random.default_rng(13)
+    E, S = 120_000, 5
+    test = (rng.integers(0, 3, size=(E, S)) * 11 + 20).astype(np.int32)
+    ref = (rng.integers(0, 3, size=(E, S)) * 2500 + 300).astype(np.int32)       # 300 / 2 800 / 5 300: first level, first level, second level
+    ref[::97, 2] = 20_000                                                     # ... and a few beyond both levels: the list
+    (p0, e0, u0), (p1, e1, u1) = _fit_both_layouts(edlib, test, ref)
+    assert u0 == 0 and u1 == 0
+    assert np.max(np.abs(p1 - p0) / p0) < 1e-7 and np.max(np.abs(e1 - e0) / e0) < 1e-9
+    for s in (0, 2):
+        op, oe = oracle.fit_mle_hist(test[:, s], ref[:, s])[:2]
+        assert abs(p1[s] - op) / op < 1e-6 and abs(e1[s] - oe) / oe < 1e-8
