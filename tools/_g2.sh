@@ -1,8 +1,6 @@
 #!/bin/bash
-# the round's closing sweeps on the final library
-mkdir -p gpurun_out/r04_z
-( timeout 400 python tools/fuzz_tables.py 200 777 2>&1 | tail -2
-  timeout 400 python tools/fuzz_parity.py 150 4242 2>&1 | tail -2
-  timeout 400 python tools/fuzz_cohort.py 150 99 2>&1 | tail -3
-  timeout 400 python tools/fuzz_more.py 120 31 2>&1 | tail -3 ) > gpurun_out/r04_z/fuzz.txt 2>&1
-cat gpurun_out/r04_z/fuzz.txt
+bash tools/profile_round.sh r04_d > /dev/null 2>&1
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+python tools/profile_publish.py r04_d > /dev/null 2>&1   # (so that the default line below finds the counters of this build)
+timeout 900 python bench.py > gpurun_out/r04_d/bench_default.json 2> gpurun_out/r04_d/bench_default.err; tail -c 300 gpurun_out/r04_d/bench_default.err; head -c 300 gpurun_out/r04_d/bench_default.json
+rm -rf gpurun_out/ks
