@@ -176,3 +176,47 @@ def test_config3_whole_cohort_200k_x_8192_on_one_gpu(edlib, oracle):
         batch.close(); plan.close()
         del test, ref
         torch.cuda.empty_cache()
+
+
+def test_config3_whole_cohort_in_the_table_driven_mode(edlib, oracle):
+    """BASELINE configs[3]'s whole cohort (200 000 x 8 192) on one GPU in emit mode 2, counts sample-major: every likelihood value within
+    the tolerance of the device's per-cell evaluation of the reference's loop, whole columns against the checker's libm flavour (0 discordant
+    states / call rows), the call table as the run-length encoding of all 1.6e9 states"""
+    torch = pytest.importorskip("torch")
+    from exomedepth_amd import synth
+    S8 = 8192
+    dev = torch.device("cuda", 0)
+    chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
+    test, ref, p, phi = synth.counts_torch(chrom_off, S8, dev, seed=20250699)
+    test, ref = test.t().contiguous(), ref.t().contiguous()           # [S][E]: R's column-major matrix
+    plan = edlib.Plan(chrom_off, start, end)
+    batch = edlib.Batch(plan, S8)
+    batch.set_emit_mode(2); batch.set_counts_layout(1)
+    try:
+        phi_f = torch.empty(S8, dtype=torch.float64, device=dev)
+        p_f = torch.empty(S8, dtype=torch.float64, device=dev)
+        batch.fit(test, ref, phi_f, p_f)
+        batch.run(test, ref, phi_f, p_f)
+        assert batch.fit_unconverged()[0] == 0 and batch.n_gsl_errors() == 0
+        chk = batch.verify_emissions_tol(test, ref, phi_f, p_f, rel_tol=1e-10, abs_tol=1e-12)
+        assert chk["compared"] == 3 * E * S8 and chk["beyond"] == 0, chk
+        assert chk["max_rel"] < 1e-12
+        calls, path = batch.calls(), batch.path()
+        phi_h, p_h = phi_f.cpu().numpy(), p_f.cpu().numpy()
+        for s in (0, 4096, 8191):
+            t = test[s].cpu().numpy(); r = ref[s].cpu().numpy()
+            ell, _ = oracle.get_loglike_matrix(phi_h[s], p_h[s], t + r, t, 1.0, oracle.LIBM)
+            epath, ecalls = oracle.callcnvs(ell, chrom_off, start, end)
+            assert np.array_equal(path[:, s].astype(np.int8), epath), ("path", s)
+            mine = calls[calls["sample"] == s]
+            assert len(mine) == len(ecalls)
+            for k, name in enumerate(("start_exon", "end_exon", "type", "nexons")):
+                assert np.array_equal(mine[name] + (1 if k < 2 else 0), ecalls[:, k].astype(np.int64)), (name, s)
+        nz = path != 0
+        ends = nz.copy()
+        ends[:-1] &= (path[:-1] != path[1:])
+        last = np.asarray(chrom_off[1:]) - 1
+        ends[last] = nz[last]
+        assert int(ends.sum()) == len(calls)
+    finally:
+        batch.close(); plan.close()
