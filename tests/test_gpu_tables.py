@@ -141,21 +141,21 @@ def test_cells_beyond_the_tables_carry_the_strict_bits(edlib, mode):
 
 @pytest.mark.parametrize("mode", MODES)
 def test_samples_the_tables_do_not_serve(edlib, mode):
-    """phi >= 1 (negative shape parameters), expected outside (0, 1), a tiny expected (ill-conditioned sum), phi = 1e-9 and 1e-4 (the
-    reference's own rounding noise exceeds the bar), NaN: no tables for
+    """phi >= 1 (negative shape parameters), expected outside (0, 1), a tiny expected (ill-conditioned sum), phi = 1e-9, 1e-4 and 3e-4 (the
+    reference's own rounding noise comes too close to the bar; 1e-3 is served), NaN: no tables for
     those samples -- every cell strict, bit for bit, error counts included -- while their neighbours use theirs"""
     E, S = 1500, 24
     chrom_off, start, end = synth.exon_design(E, 2, 4)
     test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 4, n_segments=2, mean_depth=60.0)
     phi = phi.copy(); p = p.copy()
-    phi[1] = 1.5; phi[2] = 1.0; p[3] = 0.0; p[4] = 1.0; p[5] = 1e-7; phi[6] = np.nan; p[7] = -0.2; phi[8] = 0.0; phi[9] = 1e-9; phi[10] = 1e-4; phi[11] = 3e-4
+    phi[1] = 1.5; phi[2] = 1.0; p[3] = 0.0; p[4] = 1.0; p[5] = 1e-7; phi[6] = np.nan; p[7] = -0.2; phi[8] = 0.0; phi[9] = 1e-9; phi[10] = 1e-4; phi[11] = 3e-4; phi[12] = 1e-3
     plan = ed.Plan(chrom_off, start, end)
     r = run_modes(plan, S, test, ref, phi, p, mode)
     b = r[1]["batch"]
     ll0, ll1 = r[0]["ll"], r[1]["ll"]
     for s in range(S):
         ly, lr = b.emit_tables(s)[:2]
-        if s in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+        if s in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
             assert (ly, lr) == (0, 0), s
             assert np.array_equal(bits(ll1[:, :, s]), bits(ll0[:, :, s])), s
         else:
@@ -233,7 +233,7 @@ def test_wide_parameter_grid(edlib, mode, oracle):
         if ly == 0:
             assert np.array_equal(bits(r[1]["ll"][:, :, s]), bits(r[0]["ll"][:, :, s]))
         n_tab += ly > 0
-    assert n_tab >= S // 3, n_tab
+    assert n_tab >= S // 4, n_tab
     for m in (0, 1):
         r[m]["batch"].close()
     plan.close()

@@ -27,6 +27,7 @@ def close(got, want):
 t0 = time.time()
 n_cases = n_cells = n_disc_states = n_disc_calls = n_oracle_cols = 0
 worst = 0.0
+worst_at = None
 while time.time() - t0 < budget:
     S = int(rng.choice([1, 3, 7, 8, 9, 15, 16, 17, 63, 64, 65, 130, 257, 520]))
     E = int(rng.integers(1, 60 if S > 200 else 900) * rng.choice([1, 7]))
@@ -88,7 +89,13 @@ while time.time() - t0 < budget:
             raise AssertionError(("loglik", mode, layout, E, S, C, seed, len(bad)))
         fin = np.isfinite(ll0) & (ll0 != 0)
         if fin.any():
-            worst = max(worst, float(np.max(np.abs(ll[fin] - ll0[fin]) / np.abs(ll0[fin]))))
+            rel = np.where(fin, np.abs(ll - ll0) / np.where(fin, np.abs(ll0), 1.0), 0.0)
+            w = float(rel.max())
+            if w > worst:
+                worst = w
+                e_, st_, s_ = (int(v) for v in np.unravel_index(int(np.argmax(rel)), rel.shape))
+                worst_at = dict(mode=mode, phi=float(phi[s_]), p=float(p[s_]), state=st_, obs=int(test[e_, s_]), ref=int(ref[e_, s_]), strict=float(ll0[e_, st_, s_]),
+                                mixture=mixture, a12=(1.0 - float(phi[s_])) / float(phi[s_]))
         for s in range(S):                          # samples without tables: strict bits
             if b.emit_tables(s)[0] == 0:
                 assert np.array_equal(bits(ll[:, :, s]), bits(ll0[:, :, s])), ("strict bits", mode, E, S, seed, s)
@@ -111,3 +118,4 @@ while time.time() - t0 < budget:
 print("fuzz_tables ok: %d cases, %d cells in table modes, max relative difference from strict mode %.2e, %d discordant Viterbi states, "
       "%d discordant call rows, %d columns against the checker's libm flavour, %.0f s"
       % (n_cases, n_cells, worst, n_disc_states, n_disc_calls, n_oracle_cols, time.time() - t0))
+print("  the largest difference:", worst_at)
