@@ -1,3 +1,7 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_tables.py tests/test_shim.py -x -q 2>&1 | tail -4
-timeout 900 python tools/fuzz_tables.py 420 31337 2>&1 | tail -2
+rm -rf gpurun_out/r04_d
+bash tools/profile_round.sh r04_d > /dev/null 2>&1
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python tools/profile_publish.py r04_d > /dev/null 2>&1
+timeout 900 python bench.py > gpurun_out/r04_d/bench_default.json 2> gpurun_out/r04_d/bench_default.err; tail -c 200 gpurun_out/r04_d/bench_default.err; head -c 260 gpurun_out/r04_d/bench_default.json
+rm -rf gpurun_out/ks
