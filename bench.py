@@ -368,6 +368,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
         b, _, _ = co.batch(tk)
         n_calls = b.n_calls()
         t3 = time.perf_counter()
+        tstats = b.table_stats() if emit_mode else None
         n_chosen = float(rs["n_chosen"].mean())
         checksum = int(np.sum((rs["choice"].astype(np.int64) + 1) * (np.arange(rs["choice"].shape[1], dtype=np.int64) + 1)[None, :]))
         if rep > 0:                                   # (the first repetition allocates)
@@ -379,7 +380,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
     return {"workload": "one cohort of %d samples x %d exons: counts from pinned host memory (uint16) -> reference sets of every sample against all "
                         "others (n.bins.reduced 10000, <= 32 candidates) + aggregate references on the device -> fit + emissions + Viterbi + calls; "
                         "stages one after the other (one cohort, nothing to overlap with), median of %d" % (S, E, reps),
-            **med, "value": E * S * world / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls,
+            **med, "value": E * S * world / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls, "table_stats": tstats,
             "ranks": world, "choice_checksum_rank0": checksum,
             "sharding": (None if world == 1 else "every rank: its own %d columns as tests, all %d as candidates (one all_gather of the count slabs); "
                                                   "times and counts are rank 0's" % (S, S * world))}
@@ -716,6 +717,7 @@ def main():
     if use_pg:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    table_stats = last_batch().table_stats() if (plain and not args.fused and args.emit_mode != "strict") else None    # (after the clock: the last timed step's)
     if use_pg:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -830,6 +832,10 @@ def main():
                              "`call_table` are latencies of the batch's tail on its own streams and `fit` runs on a second stream: "
                              "they overlap the emissions of the neighbouring batch and do not add up to ms_per_step",
             "n_calls": n_calls,
+            "table_stats": table_stats,
+            "table_stats_note": "table-driven emission modes, last timed step: cells on the strict lists (outside their sample's tables or under its "
+                                "few-reads rule), samples without tables (evaluated whole by the strict arithmetic) and their cells, launches whose "
+                                "lists ran out (every cell looked at again)",
             "verify": verify,
             "fit_concordance": fit_conc,
             "extra": {"config1": config1, "workflow": workflow, "other_modes": other_modes},

@@ -120,6 +120,16 @@ SYMBOLS = [
     ("ed_cohort_run_host", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, C.POINTER(_i64)]),
     ("ed_cohort_copy_calls", C.c_int, [_vp, _vp, _vp, _i64]),
     ("ed_cohort_run_status", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("ed_multi_create", C.c_int, [C.POINTER(_vp), _vp, C.c_int, _i64, _i32, _vp, _vp, _vp, _dbl, _dbl, _i64, C.c_int]),
+    ("ed_multi_destroy", None, [_vp]),
+    ("ed_multi_n_devices", C.c_int, [_vp]),
+    ("ed_multi_set_option", C.c_int, [_vp, C.c_char_p, _dbl]),
+    ("ed_multi_run_host", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, C.POINTER(_i64)]),
+    ("ed_multi_copy_calls", C.c_int, [_vp, _vp, _vp, _i64]),
+    ("ed_multi_run_status", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("ed_multi_table_status", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("ed_multi_copy_bins", C.c_int, [_vp, _vp, _vp]),
+    ("ed_multi_shares", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("ed_fit_betabin_host", C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("ed_select_reference_set_host", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64)]),
     ("ed_batch_set_fit_mode", C.c_int, [_vp, C.c_int]),
@@ -130,6 +140,9 @@ SYMBOLS = [
                                                C.POINTER(_dbl), C.POINTER(_dbl), _vp, _i64]),
     ("ed_batch_copy_emit_tables", C.c_int, [_vp, _i64, C.POINTER(_i32), _vp, _i64]),
     ("ed_batch_n_cold_cells", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("ed_batch_copy_table_dims", C.c_int, [_vp, _i64, C.POINTER(_i32)]),
+    ("ed_batch_table_stats", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("ed_cohort_table_status", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
     ("ed_free", C.c_int, [_vp]),
     ("ed_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t]),

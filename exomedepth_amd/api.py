@@ -479,6 +479,20 @@ class Batch:
         check(lib().ed_batch_n_cold_cells(self.handle, C.byref(n)))
         return n.value
 
+    TABLE_STATS = ("n_cold_cells", "n_samples_without_tables", "cold_list_overflow", "n_cells_without_tables")
+
+    def table_stats(self):
+        """table-driven modes: what the last run left to the strict arithmetic (ed_batch_table_stats)"""
+        v = (C.c_int64 * 4)()
+        check(lib().ed_batch_table_stats(self.handle, v))
+        return dict(zip(self.TABLE_STATS, (int(x) for x in v)))
+
+    def table_dims(self, sample):
+        """(Ly, Lr, Tm1, reason) of one sample in the last run (ed_batch_copy_table_dims)"""
+        d = (C.c_int32 * 4)()
+        check(lib().ed_batch_copy_table_dims(self.handle, int(sample), d))
+        return tuple(int(x) for x in d)
+
     def device_pointers(self):
         L = lib()
         return {"loglik": L.ed_batch_loglik(self.handle), "path": L.ed_batch_path(self.handle),
@@ -712,12 +726,92 @@ class Cohort:
         nu, ne = C.c_int64(0), C.c_int64(0)
         check(lib().ed_cohort_run_status(self.handle, C.byref(nu), C.byref(ne)))
         out = {"calls": calls, "info": info, "phi": phi_out, "expected": exp_out, "n_unconverged": nu.value, "n_gsl_errors": ne.value}
+        ts = (C.c_int64 * 4)()
+        check(lib().ed_cohort_table_status(self.handle, ts))
+        out["table_stats"] = dict(zip(Batch.TABLE_STATS, (int(x) for x in ts)))
         if self.phi_bins > 1:
             del out["phi"]
             out["phi_bins"], out["edges"] = np.empty((self.phi_bins, S)), np.empty((self.phi_bins + 1, S))
             check(lib().ed_cohort_copy_bins(self.handle, _ptr(out["phi_bins"]), _ptr(out["edges"])))
         if want_path:
             out["path"] = path
+        return out
+
+
+class MultiDevice:
+    """ed_cohort_run_host over several devices from ONE process (ed_multi_*; csrc/edmulti.inc): the exon design replicated per
+    device, contiguous shares of whole slabs, one host thread per device, call tables concatenated in column order.
+    devices=None: every visible device once; a device may be listed more than once."""
+
+    def __init__(self, chrom_off, start, end, slab_samples, devices=None, slabs_in_flight=2, transition_probability=1e-4,
+                 expected_cnv_length=50000.0, **options):
+        chrom_off = np.ascontiguousarray(chrom_off, dtype=np.int32)
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32)
+        self.n_exons = int(start.size)
+        self.handle = C.c_void_p()
+        dv = np.ascontiguousarray(devices, dtype=np.int32) if devices is not None else None
+        check(lib().ed_multi_create(C.byref(self.handle), _ptr(dv) if dv is not None else None, int(dv.size) if dv is not None else 0,
+                                    self.n_exons, int(chrom_off.size - 1), _ptr(chrom_off), _ptr(start), _ptr(end),
+                                    float(transition_probability), float(expected_cnv_length), int(slab_samples), int(slabs_in_flight)))
+        self.phi_bins = 1
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    @property
+    def n_devices(self):
+        return int(lib().ed_multi_n_devices(self.handle))
+
+    def set_option(self, name, value):
+        check(lib().ed_multi_set_option(self.handle, name.encode(), float(value)))
+        if name == "phi_bins":
+            self.phi_bins = int(value)
+
+    def close(self):
+        if self.handle:
+            lib().ed_multi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_host(self, test, ref, layout, phi=None, expected=None, mixture=1.0, want_path=False):
+        """as Cohort.run_host; the result also carries `shares`: [(device, first column, end column, seconds of its thread)]"""
+        test, ref = np.ascontiguousarray(test), np.ascontiguousarray(ref)
+        if test.dtype != ref.dtype or test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
+            raise ValueError("test and ref must both be int32 or both uint16")
+        S = int(test.shape[1] if layout == 0 else test.shape[0])
+        E = self.n_exons
+        ph = _f64(phi) if phi is not None else None
+        ex = _f64(expected) if expected is not None else None
+        phi_out, exp_out = np.empty(S), np.empty(S)
+        path = np.empty((E, S) if layout == 0 else (S, E), dtype=np.uint8) if want_path else None
+        n = C.c_int64(0)
+        check(lib().ed_multi_run_host(self.handle, C.c_void_p(test.ctypes.data), C.c_void_p(ref.ctypes.data), S, int(layout),
+                                      int(test.dtype.itemsize), _ptr(ph) if ph is not None else None, _ptr(ex) if ex is not None else None,
+                                      float(mixture), _ptr(phi_out), _ptr(exp_out), _ptr(path) if path is not None else None, C.byref(n)))
+        calls = np.zeros(n.value, dtype=CALL_DTYPE)
+        info = np.zeros(n.value, dtype=CALL_INFO_DTYPE)
+        check(lib().ed_multi_copy_calls(self.handle, _ptr(calls), _ptr(info), n.value))
+        nu, ne = C.c_int64(0), C.c_int64(0)
+        check(lib().ed_multi_run_status(self.handle, C.byref(nu), C.byref(ne)))
+        out = {"calls": calls, "info": info, "phi": phi_out, "expected": exp_out, "n_unconverged": nu.value, "n_gsl_errors": ne.value}
+        ts = (C.c_int64 * 4)()
+        check(lib().ed_multi_table_status(self.handle, ts))
+        out["table_stats"] = dict(zip(Batch.TABLE_STATS, (int(x) for x in ts)))
+        if self.phi_bins > 1:
+            del out["phi"]
+            out["phi_bins"], out["edges"] = np.empty((self.phi_bins, S)), np.empty((self.phi_bins + 1, S))
+            check(lib().ed_multi_copy_bins(self.handle, _ptr(out["phi_bins"]), _ptr(out["edges"])))
+        if want_path:
+            out["path"] = path
+        D = self.n_devices
+        dv, b, e, sec = (C.c_int * D)(), (C.c_int64 * D)(), (C.c_int64 * D)(), (C.c_double * D)()
+        check(lib().ed_multi_shares(self.handle, dv, b, e, sec))
+        out["shares"] = [(int(dv[i]), int(b[i]), int(e[i]), float(sec[i])) for i in range(D)]
         return out
 
 

@@ -1763,7 +1763,8 @@ struct ed_batch {
   double tab_reach = 8.0;        // a table covers this multiple of the sample's mean count (+ 64)
   int64_t tab_stride = 0;        // entries between the tables of consecutive samples = 2 (capY + capR)
   double* d_tabs = nullptr;      // [S][tab_stride][3]
-  int2* d_tdims = nullptr;       // [S + 64] (Ly, Lr) per sample
+  int4* d_tdims = nullptr;       // [S + 64] (Ly, Lr, Tm1, reason) per sample (edtab.inc: tab_dims_of)
+  unsigned int* d_notab = nullptr;   // [1 + S] samples without tables: their number, then the samples (k_tab_build)
   unsigned long long* d_tacc = nullptr;   // [3][S] subsampled count sums (k_tab_stats)
   uint2* d_cold_list = nullptr;  // cells outside their sample's tables
   unsigned int* d_cold_n = nullptr;
@@ -2171,7 +2172,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   A((void**)&b->d_counts, (size_t)S * std::max<int64_t>(C, 1) * 4);
   A((void**)&b->d_offsets, (size_t)S * std::max<int64_t>(C, 1) * 8);
   A((void**)&b->d_total, 8);
-  A((void**)&b->d_nerr, 16);   // [0..7] GSL error events, [8..11] "cold tasks were left out" flag of k_emit_batch
+  A((void**)&b->d_nerr, 64);   // [0..7] GSL error events, [8..11] "cold tasks were left out" flag of k_emit_batch, [16..39] table-mode counters (k_tab_cold)
   A((void**)&b->d_calls, (size_t)b->calls_cap * sizeof(ed_call));
   if (!ok)
     return ed_fail(ED_ERR_NOMEM, "ed_batch_create: device allocation failed (E=%lld S=%lld)", (long long)E, (long long)S);
@@ -2300,7 +2301,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   if (!b) return;
   fitwork_free(b->fitw);
   binswork_free(b->binsw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t, b->d_test_sm, b->d_ref_sm, b->d_loglik_sm, b->d_blk_sm};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_notab, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t, b->d_test_sm, b->d_ref_sm, b->d_loglik_sm, b->d_blk_sm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -2423,6 +2424,14 @@ constexpr int kBinsRtab = 8192;    // reference counts covered by the table of t
 // ---- table-driven emission mode (edtab.inc): buffers, segment table, the per-run table build ----
 static int64_t tab_rows_per_wg(int tw) { return 4 * (64 / tw); }
 
+static void tab_release(ed_batch* b)
+{
+  void** ptrs[] = {(void**)&b->d_tabs, (void**)&b->d_tdims, (void**)&b->d_notab, (void**)&b->d_tacc, (void**)&b->d_cold_list, (void**)&b->d_cold_n, (void**)&b->d_seg_t};
+  for (void** q : ptrs) { if (*q) (void)hipFree(*q); *q = nullptr; }
+  (void)hipGetLastError();
+}
+
+// all of the mode's buffers or none (a half-made set must not pass for a made one on the next call: ADVICE r4)
 static int tab_setup(ed_batch* b)
 {
   if (b->d_tabs) return ED_OK;
@@ -2433,16 +2442,6 @@ static int tab_setup(ed_batch* b)
     return ed_fail(ED_ERR_INVALID, "emit mode 1: %d samples x %lld table entries x 24 bytes per tile exceed 2^31 (smaller table caps or tile width)",
                    b->tab_tw, (long long)b->tab_stride);
   b->cold_cap = (unsigned int)std::min<int64_t>(std::max<int64_t>(E * S / 32, 1 << 16), (int64_t)1 << 28) / kColdLists * kColdLists;
-  bool ok = true;
-  auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) ok = false; };
-  A((void**)&b->d_tabs, (size_t)S * b->tab_stride * 24);
-  A((void**)&b->d_tdims, (size_t)(S + 64) * 8);
-  A((void**)&b->d_tacc, (size_t)3 * S * 8);
-  A((void**)&b->d_cold_list, (size_t)b->cold_cap * 8);
-  A((void**)&b->d_cold_n, (size_t)(kColdLists + 1) * 4);
-  if (!ok) return ed_fail(ED_ERR_NOMEM, "emit mode 1: cannot allocate the tables (%lld bytes for %lld samples)",
-                          (long long)(S * b->tab_stride * 24), (long long)S);
-  HIP_TRY(hipMemset(b->d_tdims, 0, (size_t)(S + 64) * 8));
   // segments in job order, workgroups numbered for k_emit_tab's tile (rows x tab_tw samples), as ed_batch_create does for k_emit_batch
   const int64_t rows = tab_rows_per_wg(b->tab_tw), nsb = (S + b->tab_tw - 1) / b->tab_tw;
   int64_t blk = 0;
@@ -2455,8 +2454,23 @@ static int tab_setup(ed_batch* b)
     blk += (nsb >= 8) ? ((neb + kTabRun - 1) / kTabRun) * (int64_t)kTabRun * 8 * ((nsb + 7) / 8) : neb * nsb;
   }
   b->seg_t.push_back(blk); b->seg_t.push_back(0); b->seg_t.push_back(0);
-  HIP_TRY(hipMalloc((void**)&b->d_seg_t, b->seg_t.size() * 8));
-  HIP_TRY(hipMemcpy(b->d_seg_t, b->seg_t.data(), b->seg_t.size() * 8, hipMemcpyHostToDevice));
+  bool ok = true;
+  auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) { ok = false; *q = nullptr; } };
+  A((void**)&b->d_tabs, (size_t)S * b->tab_stride * 24);
+  A((void**)&b->d_tdims, (size_t)(S + 64) * 16);
+  A((void**)&b->d_notab, (size_t)(S + 1) * 4);
+  A((void**)&b->d_tacc, (size_t)3 * S * 8);
+  A((void**)&b->d_cold_list, (size_t)b->cold_cap * 8);
+  A((void**)&b->d_cold_n, (size_t)(kColdLists + 1) * 4);
+  A((void**)&b->d_seg_t, b->seg_t.size() * 8);
+  if (ok && hipMemset(b->d_tdims, 0, (size_t)(S + 64) * 16) != hipSuccess) ok = false;
+  if (ok && hipMemset(b->d_notab, 0, (size_t)(S + 1) * 4) != hipSuccess) ok = false;
+  if (ok && hipMemcpy(b->d_seg_t, b->seg_t.data(), b->seg_t.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+  if (!ok) {
+    tab_release(b);
+    return ed_fail(ED_ERR_NOMEM, "emit mode 1: cannot allocate the tables (%lld bytes for %lld samples)",
+                   (long long)(S * b->tab_stride * 24), (long long)S);
+  }
   return ED_OK;
 }
 
@@ -2466,13 +2480,6 @@ static int tab_setup_sm(ed_batch* b)
   const ed_plan* p = b->plan;
   const int64_t S = b->S, E = p->E;
   b->Epad = ((E + 15) / 16) * 16 + 64;    // (k_viterbi_sm loads whole tiles up to three tiles past a chromosome's end)
-  bool ok = true;
-  auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) ok = false; };
-  A((void**)&b->d_test_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
-  A((void**)&b->d_ref_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
-  A((void**)&b->d_loglik_sm, ((size_t)S * 3 * b->Epad + 512) * 8);
-  if (!ok) return ed_fail(ED_ERR_NOMEM, "emit mode 2: cannot allocate the sample-major matrices (E=%lld S=%lld)", (long long)E, (long long)S);
-  HIP_TRY(hipMemset(b->d_loglik_sm, 0, ((size_t)S * 3 * b->Epad + 512) * 8));
   // Blocks of 64 exons on the ABSOLUTE exon grid, clipped to their chromosome: every block but the first and last of a chromosome
   // starts at a multiple of 64 exons, so that a wave's three 512-byte stores are whole aligned 128-byte lines of the [S][3][Epad]
   // matrix (chromosome-relative blocks made nearly every store begin and end with a partial line).
@@ -2491,8 +2498,20 @@ static int tab_setup_sm(ed_batch* b)
   b->seg_sm.push_back(blk); b->seg_sm.push_back(0); b->seg_sm.push_back(0);
   if (bm.empty()) bm.push_back(make_int2(0, 0));
   b->nblk_sm = (int64_t)bm.size();
-  HIP_TRY(hipMalloc((void**)&b->d_blk_sm, bm.size() * 8));
-  HIP_TRY(hipMemcpy(b->d_blk_sm, bm.data(), bm.size() * 8, hipMemcpyHostToDevice));
+  bool ok = true;
+  auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) { ok = false; *q = nullptr; } };
+  A((void**)&b->d_test_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
+  A((void**)&b->d_ref_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
+  A((void**)&b->d_blk_sm, bm.size() * 8);
+  A((void**)&b->d_loglik_sm, ((size_t)S * 3 * b->Epad + 512) * 8);     // (last: it is the "already set up" sentinel)
+  if (ok && hipMemset(b->d_loglik_sm, 0, ((size_t)S * 3 * b->Epad + 512) * 8) != hipSuccess) ok = false;
+  if (ok && hipMemcpy(b->d_blk_sm, bm.data(), bm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+  if (!ok) {     // all of them or none
+    void** ptrs[] = {(void**)&b->d_test_sm, (void**)&b->d_ref_sm, (void**)&b->d_blk_sm, (void**)&b->d_loglik_sm};
+    for (void** q : ptrs) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    (void)hipGetLastError();
+    return ed_fail(ED_ERR_NOMEM, "emit mode 2: cannot allocate the sample-major matrices (E=%lld S=%lld)", (long long)E, (long long)S);
+  }
   return ED_OK;
 }
 
@@ -2520,13 +2539,14 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
   const int64_t E = b->plan->E, S = b->S;
   const int step = E >= 4096 ? 16 : 1;
   HIP_TRY(hipMemsetAsync(b->d_tacc, 0, (size_t)3 * S * 8, st));
+  HIP_TRY(hipMemsetAsync(b->d_notab, 0, 4, st));
   if (E > 0 && b->counts_layout == 1)
     hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc);
   else if (E > 0)
     hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
                        step, b->d_tacc);
   hipLaunchKernelGGL(k_tab_build, dim3((unsigned)S, 3), dim3(kTabBlock), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach, b->tab_capY, b->tab_capR,
-                     b->d_tdims, S, b->d_tabs, b->tab_stride);
+                     b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab);
   HIP_TRY(hipGetLastError());
   return ED_OK;
 }
@@ -2581,7 +2601,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   b->split_recorded = false;
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected; b->last_layout = b->counts_layout;
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
-  HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 16, st));
+  HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 64, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
   const bool ready = plain && b->prepared && b->prepared_phi == d_phi && b->prepared_exp == d_expected && b->prepared_mix == mixture && !b->fused;
   b->prepared = false;
@@ -2719,10 +2739,13 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         b->split_recorded = true;
       }
       emit_launch(nblk - head - cut, blk0 + head + cut);
-      if (tabm && nblk > 0)    // the cells outside their sample's tables (returns at once when there are none)
-        hipLaunchKernelGGL(k_tab_cold, dim3(1024), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_cflags, b->d_tdims, b->d_cold_list, b->d_cold_n,
+      if (tabm && nblk > 0) {  // the cells outside their sample's tables and the samples without tables (returns at once when there are none)
+        const bool csm = cl1 || tabsm;       // counts walked sample-major ([S][E]: the caller's, or this mode's transposed copy)
+        hipLaunchKernelGGL(k_tab_cold, dim3(1024), dim3(256), 0, st, csm ? (cl1 ? d_test : b->d_test_sm) : d_test, csm ? (cl1 ? d_ref : b->d_ref_sm) : d_ref,
+                           b->d_consts, b->d_cflags, b->d_tdims, b->d_cold_list, b->d_cold_n,
                            b->cold_cap, b->d_seg_t, j0, j1, S, tabsm ? b->d_loglik_sm : b->d_loglik, b->d_nerr, tabsm ? (int64_t)1 : 3 * S,
-                           tabsm ? b->Epad : S, tabsm ? 3 * b->Epad : (int64_t)1, cl1 ? (int64_t)1 : S, cl1 ? E : (int64_t)1);
+                           tabsm ? b->Epad : S, tabsm ? 3 * b->Epad : (int64_t)1, csm ? (int64_t)1 : S, csm ? E : (int64_t)1, b->d_notab, b->d_nerr + 2);
+      }
       else if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
         hipLaunchKernelGGL(k_emit_cold, dim3(512), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_seg, j0, j1, S, b->d_loglik,
                            b->d_nerr, cold_flag);
@@ -3256,8 +3279,8 @@ ED_EXPORT int ed_batch_copy_emit_tables(ed_batch* b, int64_t sample, int32_t dim
   if (int rc = batch_ready(b)) return rc;
   if (!dims || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_emit_tables: bad arguments");
   if (!b->d_tabs || b->emit_mode < 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_emit_tables: the batch does not run a table-driven emit mode");
-  int2 d;
-  if (int rc = ed_d2h(&d, b->d_tdims + sample, 8, b->stream)) return rc;
+  int4 d;
+  if (int rc = ed_d2h(&d, b->d_tdims + sample, 16, b->stream)) return rc;
   dims[0] = d.x; dims[1] = d.y;
   const int64_t n = std::min<int64_t>(2 * ((int64_t)d.x + d.y), cap_entries);
   if (n > 0) {
@@ -3267,16 +3290,42 @@ ED_EXPORT int ed_batch_copy_emit_tables(ed_batch* b, int64_t sample, int32_t dim
   return ED_OK;
 }
 
-// emit mode 1: cells the last emission launch group of the last run handed to the strict arithmetic (outside their sample's tables)
-ED_EXPORT int ed_batch_n_cold_cells(ed_batch* b, int64_t* n_cells)
+// table-driven modes: what the last run left to the strict arithmetic
+//   out[0] cells on the strict lists (outside their sample's tables, or under its few-reads rule), summed over the run's launch groups
+//   out[1] samples without tables (walked whole by the strict pass)      out[2] launch groups whose lists ran out (full re-scan)
+//   out[3] cells of the samples without tables
+ED_EXPORT int ed_batch_table_stats(ed_batch* b, int64_t out[4])
 {
   if (int rc = batch_ready(b)) return rc;
+  if (!out) return ed_fail(ED_ERR_INVALID, "NULL output");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!b->d_cold_n || b->emit_mode < 1) return ED_OK;
+  unsigned long long v[3] = {0, 0, 0};
+  unsigned int nnt = 0;
+  if (int rc = ed_d2h(v, b->d_nerr + 2, 24, b->stream)) return rc;
+  if (int rc = ed_d2h(&nnt, b->d_notab, 4, b->stream)) return rc;
+  out[0] = (int64_t)v[0]; out[1] = (int64_t)nnt; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
+  return ED_OK;
+}
+
+ED_EXPORT int ed_batch_n_cold_cells(ed_batch* b, int64_t* n_cells)
+{
   if (!n_cells) return ed_fail(ED_ERR_INVALID, "NULL output");
-  *n_cells = 0;
-  if (!b->d_cold_n) return ED_OK;
-  std::vector<unsigned int> v((size_t)kColdLists + 1, 0u);
-  if (int rc = ed_d2h(v.data(), b->d_cold_n, v.size() * 4, b->stream)) return rc;
-  for (int i = 0; i < kColdLists; ++i) *n_cells += (int64_t)v[(size_t)i];
+  int64_t v[4];
+  if (int rc = ed_batch_table_stats(b, v)) return rc;
+  *n_cells = v[0];
+  return ED_OK;
+}
+
+// one sample's (Ly, Lr, Tm1, reason) of the last run (edtab.inc: tab_dims_of)
+ED_EXPORT int ed_batch_copy_table_dims(ed_batch* b, int64_t sample, int32_t dims[4])
+{
+  if (int rc = batch_ready(b)) return rc;
+  if (!dims || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_table_dims: bad arguments");
+  if (!b->d_tabs || b->emit_mode < 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_table_dims: the batch does not run a table-driven emit mode");
+  int4 d;
+  if (int rc = ed_d2h(&d, b->d_tdims + sample, 16, b->stream)) return rc;
+  dims[0] = d.x; dims[1] = d.y; dims[2] = d.z; dims[3] = d.w;
   return ED_OK;
 }
 
@@ -3304,4 +3353,5 @@ ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
 #include "edbins.inc"
 #include "edcov.inc"
 #include "edcohort.inc"
+#include "edmulti.inc"
 #include "edrefcohort.inc"

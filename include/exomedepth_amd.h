@@ -311,10 +311,18 @@ int ed_batch_set_emit_tables(ed_batch* batch, int32_t cap_obs, int32_t cap_ref, 
 int ed_batch_verify_emissions_tol(ed_batch* batch, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
                                   const double* d_expected, double mixture, double rel_tol, double abs_tol, int64_t* n_compared,
                                   int64_t* n_beyond, double* max_rel, double* max_abs, ed_emit_mismatch* first, int64_t cap);
-/* emit mode 1 diagnostics: one sample's tables as the last run built them -- dims = (Ly, Lr); entries [2 (Ly + Lr)][3]: the obs
- * table (Ly entries), the ref table (Lr), the tot table (Ly + Lr), each entry (deletion, normal, duplication) -- and the number
- * of cells the last run's (last group of) emissions handed to the strict arithmetic. */
+/* Table-mode diagnostics: one sample's tables as the last run built them -- dims = (Ly, Lr); entries [2 (Ly + Lr)][3]: the obs
+ * table (Ly entries), the ref table (Lr), the tot table (Ly + Lr), each entry (deletion, normal, duplication).
+ * ed_batch_copy_table_dims: (Ly, Lr, Tm1, reason) of a sample -- a cell is served by the tables when obs < Ly, ref < Lr and not
+ * 0 < tot <= Tm1 (few reads under a nearly binomial model: the REFERENCE's value is too noisy there for a 1e-10 relative comparison);
+ * reason != 0 = the sample has no tables (1 GSL error in a per-sample constant, 2 shape parameters not positive normal numbers,
+ * 3 ill-conditioned at any useful table length, 4 too many few-read cells) and is evaluated whole by the strict arithmetic.
+ * ed_batch_table_stats: what the last run left to the strict arithmetic -- out[0] cells on the strict lists (all launch groups),
+ * out[1] samples without tables, out[2] launch groups whose lists ran out (every cell looked at again), out[3] cells of the
+ * samples without tables.  ed_batch_n_cold_cells = out[0]. */
 int ed_batch_copy_emit_tables(ed_batch* batch, int64_t sample, int32_t dims[2], double* entries, int64_t cap_entries);
+int ed_batch_copy_table_dims(ed_batch* batch, int64_t sample, int32_t dims[4]);
+int ed_batch_table_stats(ed_batch* batch, int64_t out[4]);
 int ed_batch_n_cold_cells(ed_batch* batch, int64_t* n_cells);
 
 /* Per-stage device times of the last ed_batch_run / ed_batch_fit, measured with HIP events on the
@@ -522,9 +530,38 @@ int ed_cohort_run_host(ed_cohort* cohort, const void* test, const void* ref, int
                        uint8_t* path_out, int64_t* n_calls);
 int ed_cohort_copy_calls(ed_cohort* cohort, ed_call* calls, ed_call_info* info, int64_t cap);
 int ed_cohort_run_status(ed_cohort* cohort, int64_t* n_unconverged, int64_t* n_gsl_errors);
+/* table-driven emit modes: ed_batch_table_stats summed over the slabs of the last ed_cohort_run_host */
+int ed_cohort_table_status(ed_cohort* cohort, int64_t out[4]);
 /* option phi_bins > 1, after ed_cohort_run_host (whose phi_out is not written in that mode): phi.estimates [phi_bins][n_total] and
  * complete.bins [(phi_bins + 1)][n_total] of the whole cohort */
 int ed_cohort_copy_bins(ed_cohort* cohort, double* phi_bins_out, double* edges_out);
+
+/* ---- one process, several devices --------------------------------------------------------------------------------------
+ * ed_cohort_run_host over every device of the node.  The reference's user loops over the samples of a cohort in one R process
+ * (vignette/vignette.Rnw:390-431) and the samples are independent (R/class_definition.R:82-191, :311-419 see one test vector each), so
+ * nothing is exchanged on the path: the plan is replicated on every device, the cohort's columns are cut into one contiguous share of
+ * whole slabs per device, one host thread per device drives an ordinary cohort pipeline over its share (reading the caller's host
+ * matrices in place, writing its windows of the outputs), and the compact call tables are concatenated in device order = column
+ * order.  Results are those of ed_cohort_run_host on one device, bit for bit.
+ *   devices / n_devices   HIP device ordinals; NULL / 0 = every visible device once.  A device may be named more than once
+ *                         (two pipelines on one GPU: how a single-GPU box exercises the threads and the merge)
+ *   the plan arguments as ed_plan_create, slab_samples / slabs_in_flight as ed_cohort_create, options as ed_cohort_set_option
+ * ed_multi_run_host / _copy_calls / _run_status / _table_status / _copy_bins: as their ed_cohort_* namesakes, over all devices.
+ * ed_multi_shares: columns [begin[i], end[i]) device i took in the last run and the wall seconds of its thread. */
+typedef struct ed_multi ed_multi;
+int ed_multi_create(ed_multi** multi, const int* devices, int n_devices, int64_t n_exons, int32_t n_chrom, const int32_t* chrom_off,
+                    const int32_t* start, const int32_t* end, double transition_probability, double expected_cnv_length,
+                    int64_t slab_samples, int slabs_in_flight);
+void ed_multi_destroy(ed_multi* multi);
+int ed_multi_n_devices(const ed_multi* multi);
+int ed_multi_set_option(ed_multi* multi, const char* name, double value);
+int ed_multi_run_host(ed_multi* multi, const void* test, const void* ref, int64_t n_total, int layout, int wire, const double* phi,
+                      const double* expected, double mixture, double* phi_out, double* expected_out, uint8_t* path_out, int64_t* n_calls);
+int ed_multi_copy_calls(ed_multi* multi, ed_call* calls, ed_call_info* info, int64_t cap);
+int ed_multi_run_status(ed_multi* multi, int64_t* n_unconverged, int64_t* n_gsl_errors);
+int ed_multi_table_status(ed_multi* multi, int64_t out[4]);
+int ed_multi_copy_bins(ed_multi* multi, double* phi_bins_out, double* edges_out);
+int ed_multi_shares(ed_multi* multi, int* devices, int64_t* begin, int64_t* end, double* seconds);
 
 /* The model fit of new('ExomeDepth') alone, for every column of a host-resident cohort: what stands where the reference calls
  * aod::betabin(cbind(test, reference) ~ 1, random = ~ 1) and fitted(mod) (R/class_definition.R:118-119, :168).  layout / wire as

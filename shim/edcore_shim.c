@@ -95,13 +95,12 @@ static void set_names(SEXP list, const char *const *names, int n)
 
 /* device objects of one .Call, owned by an external pointer (released by the call itself on every return path, by its finalizer if
  * an R error unwound the call) */
-typedef struct { ed_plan *plan; ed_cohort *co; } edr_guard;
+typedef struct { ed_multi *multi; } edr_guard;
 static void edr_guard_release(SEXP p)
 {
   edr_guard *g = (edr_guard *) R_ExternalPtrAddr(p);
   if (!g) return;
-  if (g->co) ed_cohort_destroy(g->co);
-  if (g->plan) ed_plan_destroy(g->plan);
+  if (g->multi) ed_multi_destroy(g->multi);
   free(g);
   R_ClearExternalPtr(p);
 }
@@ -117,13 +116,17 @@ static void edr_guard_release(SEXP p)
  *   want_path         integer 0/1: also return the Viterbi state of every exon (raw n_exons x n_samples)
  *   phi_bins          the reference's phi.bins (R/class_definition.R:86, :120-147): 1 = one dispersion per sample; 2..8 = one per depth
  *                     level of the reference counts, phi.linear interpolated per exon (phi / expected cannot be given then)
+ *   devices           integer vector of HIP device ordinals, or NULL = every visible device: the samples are independent
+ *                     (vignette/vignette.Rnw:390-431 loops over them), so the cohort's columns are dealt to the devices as contiguous
+ *                     shares of whole slabs, one host thread per device (include/exomedepth_amd.h: ed_multi_*); R objects are touched
+ *                     by the calling thread only -- the worker threads see plain C arrays
  * Value: list(sample, start.p, end.p, type, nexons, BF, reads.expected, reads.observed, reads.ratio  -- one element per call,
  *             ordered by (sample, chromosome, position); sample / start.p / end.p 1-based, type 1 = deletion 2 = duplication --
  *             phi, expected (double[n_samples]), path (raw matrix or NULL), n.unconverged, n.gsl.errors,
  *             phi.bins (phi_bins x n_samples: phi.estimates per level; NULL for phi_bins = 1; `phi` is NA then),
  *             complete.bins ((phi_bins + 1) x n_samples: the level edges, :125-126; NULL for phi_bins = 1)) */
 SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, SEXP end, SEXP tprob, SEXP ecl, SEXP phi,
-                        SEXP expected, SEXP prop_tumor, SEXP slab, SEXP want_path, SEXP fit_mode, SEXP phi_bins, SEXP emit_mode)
+                        SEXP expected, SEXP prop_tumor, SEXP slab, SEXP want_path, SEXP fit_mode, SEXP phi_bins, SEXP emit_mode, SEXP devices)
 {
   const int B = INTEGER(phi_bins)[0];
   const int em = INTEGER(emit_mode)[0];      /* 0 strict, 1 tables (tiles), 2 tables sample-major (include/exomedepth_amd.h: ed_batch_set_emit_mode) */
@@ -147,20 +150,25 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
   if (!gd) Rf_error("exomedepth_amd: out of memory");
   R_SetExternalPtrAddr(guard, gd);
   R_RegisterCFinalizerEx(guard, edr_guard_release, TRUE);
-  if (ed_plan_create(&gd->plan, 0, E, C, INTEGER(chrom_off), INTEGER(start), INTEGER(end), REAL(tprob)[0], REAL(ecl)[0]) != ED_OK) {
+  const int n_dev = devices == R_NilValue ? 0 : (int)XLENGTH(devices);
+  int sl = INTEGER(slab)[0];
+  if (sl <= 0 || sl > S) sl = S;
+  {                       /* every device gets a share: no slab wider than the cohort's width over the devices */
+    const int nd = n_dev > 0 ? n_dev : ed_device_count();
+    if (nd > 1 && sl > (S + nd - 1) / nd) sl = (S + nd - 1) / nd;
+  }
+  int rc = ed_multi_create(&gd->multi, n_dev > 0 ? INTEGER(devices) : NULL, n_dev, E, C, INTEGER(chrom_off), INTEGER(start), INTEGER(end),
+                           REAL(tprob)[0], REAL(ecl)[0], sl, 2);
+  if (rc != ED_OK) {
     edr_guard_release(guard);
     Rf_error("exomedepth_amd: %s", ed_last_error());
   }
-  ed_plan *plan = gd->plan;
-  int sl = INTEGER(slab)[0];
-  if (sl <= 0 || sl > S) sl = S;
-  int rc = ed_cohort_create(&gd->co, plan, sl, 2);
-  ed_cohort *co = gd->co;
-  if (rc == ED_OK) rc = ed_cohort_set_option(co, "fit_mode", (double)INTEGER(fit_mode)[0]);
-  if (rc == ED_OK && B > 1) rc = ed_cohort_set_option(co, "phi_bins", (double)B);
-  if (rc == ED_OK && B == 1 && em > 0) rc = ed_cohort_set_option(co, "emit_mode", (double)em);
+  ed_multi *co = gd->multi;
+  if (rc == ED_OK) rc = ed_multi_set_option(co, "fit_mode", (double)INTEGER(fit_mode)[0]);
+  if (rc == ED_OK && B > 1) rc = ed_multi_set_option(co, "phi_bins", (double)B);
+  if (rc == ED_OK && B == 1 && em > 0) rc = ed_multi_set_option(co, "emit_mode", (double)em);
   /* R's column-major exons x samples matrix IS the sample-major layout emit mode 2 works in: uploaded as it lies, no transposition */
-  if (rc == ED_OK && B == 1 && em == 2) rc = ed_cohort_set_option(co, "counts_layout", 1.0);
+  if (rc == ED_OK && B == 1 && em == 2) rc = ed_multi_set_option(co, "counts_layout", 1.0);
   SEXP out = R_NilValue;
   int64_t n = 0;
   if (rc == ED_OK) {
@@ -168,14 +176,14 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
     SEXP rexp = PROTECT(allocVector(REALSXP, S)); nprot++;
     SEXP rpath = R_NilValue;
     if (INTEGER(want_path)[0]) { rpath = PROTECT(allocMatrix(RAWSXP, E, S)); nprot++; }
-    rc = ed_cohort_run_host(co, INTEGER(test), INTEGER(reference), S, 1 /* R's column-major */, 4, given ? REAL(phi) : NULL,
+    rc = ed_multi_run_host(co, INTEGER(test), INTEGER(reference), S, 1 /* R's column-major */, 4, given ? REAL(phi) : NULL,
                             given ? REAL(expected) : NULL, mix, REAL(rphi), REAL(rexp), rpath != R_NilValue ? RAW(rpath) : NULL, &n);
     if (rc == ED_OK) {
       ed_call *calls = (ed_call *) R_alloc((size_t)(n > 0 ? n : 1), sizeof(ed_call));
       ed_call_info *info = (ed_call_info *) R_alloc((size_t)(n > 0 ? n : 1), sizeof(ed_call_info));
-      rc = ed_cohort_copy_calls(co, calls, info, n);
+      rc = ed_multi_copy_calls(co, calls, info, n);
       int64_t nu = 0, ne = 0;
-      if (rc == ED_OK) rc = ed_cohort_run_status(co, &nu, &ne);
+      if (rc == ED_OK) rc = ed_multi_run_status(co, &nu, &ne);
       if (rc == ED_OK) {
         static const char *const names[] = {"sample", "start.p", "end.p", "type", "nexons", "BF", "reads.expected", "reads.observed",
                                             "reads.ratio", "phi", "expected", "path", "n.unconverged", "n.gsl.errors", "phi.bins",
@@ -208,7 +216,7 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
         if (B > 1) {
           /* [level][sample] row-major on the library's side = the n_samples x levels matrix column-major: transposed here */
           double *pb = (double *) R_alloc((size_t)B * S, sizeof(double)), *eb = (double *) R_alloc((size_t)(B + 1) * S, sizeof(double));
-          rc = ed_cohort_copy_bins(co, pb, eb);
+          rc = ed_multi_copy_bins(co, pb, eb);
           if (rc == ED_OK) {
             SEXP rpb = allocMatrix(REALSXP, B, S); SET_VECTOR_ELT(out, 14, rpb);
             SEXP reb = allocMatrix(REALSXP, B + 1, S); SET_VECTOR_ELT(out, 15, reb);
@@ -337,7 +345,7 @@ static const R_CallMethodDef CallEntries[] = {                                /*
   {"C_hmm",              (DL_FUNC) &C_hmm,              6},
   {"get_loglike_matrix", (DL_FUNC) &get_loglike_matrix, 5},
   /* cohort-level entries of this library (not in the reference) */
-  {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      15},
+  {"ed_call_cnvs_batch",      (DL_FUNC) &edr_call_cnvs_batch,      16},
   {"ed_fit_betabin_batch",    (DL_FUNC) &edr_fit_betabin_batch,    3},
   {"ed_select_reference_set", (DL_FUNC) &edr_select_reference_set, 4},
   {"ed_cohort_reference_sets", (DL_FUNC) &edr_cohort_reference_sets, 4},

@@ -26,7 +26,27 @@ def close(got, want):
     return ok
 
 
+def close_rel(got, want):
+    """north_star's bar as written: 1e-10 RELATIVE, no absolute floor (equal values -- zeros, infinities -- and NaN for NaN pass)"""
+    return (np.isnan(got) & np.isnan(want)) | (got == want) | (np.abs(got - want) <= REL_TOL * np.abs(want))
+
+
 MODES = (1, 2)     # 1: exon-major tiles, tables through the caches; 2: sample-major, tables in LDS
+
+
+def not_served(b, test, ref):
+    """[E][S] mask of the cells the tables of the last run do not serve (ed_batch_copy_table_dims: outside (Ly, Lr), or 0 < tot <= Tm1),
+    and the [S] mask of samples without tables"""
+    E, S = test.shape
+    out = np.zeros((E, S), dtype=bool)
+    notab = np.zeros(S, dtype=bool)
+    for s in range(S):
+        ly, lr, tm1, reason = b.table_dims(s)
+        t, r = test[:, s].astype(np.int64), ref[:, s].astype(np.int64)
+        out[:, s] = ~((t >= 0) & (t < ly) & (r >= 0) & (r < lr)) | ((t + r >= 1) & (t + r <= tm1))
+        notab[s] = ly == 0
+        assert (reason != 0) == (ly == 0)
+    return out, notab
 
 
 def run_modes(plan, S, test, ref, phi, p, mode=1, **tab_opts):
@@ -121,14 +141,13 @@ def test_cells_beyond_the_tables_carry_the_strict_bits(edlib, mode):
     for reach, cap_obs, cap_ref in ((1.0, 64, 64), (1.0, 128, 1024), (8.0, 4096, 32768)):
         r = run_modes(plan, S, test, ref, phi, p, mode, cap_obs=cap_obs, cap_ref=cap_ref, reach=reach)
         b = r[1]["batch"]
-        ncold = b.n_cold_cells()
         ll0, ll1 = r[0]["ll"], r[1]["ll"]
-        out = np.zeros((E, S), dtype=bool)
-        for s in range(S):
-            ly, lr = b.emit_tables(s)[:2]
-            out[:, s] = ~((test[:, s] >= 0) & (test[:, s] < ly) & (ref[:, s] >= 0) & (ref[:, s] < lr))
-        # with one emission launch group the counter is the batch's; with overlap groups it is the last group's: bound it
-        assert ncold <= out.sum() and (out.sum() == 0) == (ncold == 0)
+        out, notab = not_served(b, test, ref)
+        assert not notab.any()
+        st = b.table_stats()
+        assert st["n_cold_cells"] == out.sum() == b.n_cold_cells(), (st, out.sum())     # summed over the launch groups, lists run out or not
+        assert st["n_samples_without_tables"] == 0 and st["n_cells_without_tables"] == 0
+        assert (st["cold_list_overflow"] > 0) if cap_ref == 64 else (st["cold_list_overflow"] == 0 or reach < 8.0), st
         sel = np.broadcast_to(out[:, None, :], ll0.shape)
         assert np.array_equal(bits(ll1[sel]), bits(ll0[sel]))                 # strict bits (NaN payloads included)
         assert np.all(close(ll1[~sel], ll0[~sel]))
@@ -141,31 +160,123 @@ def test_cells_beyond_the_tables_carry_the_strict_bits(edlib, mode):
 
 @pytest.mark.parametrize("mode", MODES)
 def test_samples_the_tables_do_not_serve(edlib, mode):
-    """phi >= 1 (negative shape parameters), expected outside (0, 1), a tiny expected (ill-conditioned sum), phi = 1e-9, 1e-4 and 3e-4 (the
-    reference's own rounding noise comes too close to the bar; 1e-3 is served), NaN: no tables for
-    those samples -- every cell strict, bit for bit, error counts included -- while their neighbours use theirs"""
+    """phi >= 1 (negative shape parameters), expected outside (0, 1), a tiny expected (ill-conditioned sum), phi = 1e-9 (binomial: every cell
+    under the few-reads rule), NaN: no tables for those samples -- every cell strict, bit for bit, error counts included, in one pass over
+    the whole sample -- while their neighbours use theirs.  phi = 1e-4 and 3e-4 (nearly binomial) keep their tables and lose only the
+    cells with few reads (the reference's own rounding noise is too close to the bar there)."""
     E, S = 1500, 24
     chrom_off, start, end = synth.exon_design(E, 2, 4)
     test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 4, n_segments=2, mean_depth=60.0)
     phi = phi.copy(); p = p.copy()
     phi[1] = 1.5; phi[2] = 1.0; p[3] = 0.0; p[4] = 1.0; p[5] = 1e-7; phi[6] = np.nan; p[7] = -0.2; phi[8] = 0.0; phi[9] = 1e-9; phi[10] = 1e-4; phi[11] = 3e-4; phi[12] = 1e-3
+    test[:30, 10] = [0, 1, 2] * 10; ref[:30, 10] = [1, 0, 3] * 10       # cells with 1 .. 5 reads in the nearly binomial sample
     plan = ed.Plan(chrom_off, start, end)
     r = run_modes(plan, S, test, ref, phi, p, mode)
     b = r[1]["batch"]
     ll0, ll1 = r[0]["ll"], r[1]["ll"]
+    out, notab = not_served(b, test, ref)
+    assert list(np.flatnonzero(notab)) == [1, 2, 3, 4, 5, 6, 7, 8, 9]
+    assert b.table_dims(10)[2] >= 5 and b.table_dims(11)[2] >= 1 and b.table_dims(12)[2] == 0 and b.table_dims(0)[2] == 0
+    assert out[:30, 10].all()
     for s in range(S):
-        ly, lr = b.emit_tables(s)[:2]
-        if s in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
-            assert (ly, lr) == (0, 0), s
+        if notab[s]:
             assert np.array_equal(bits(ll1[:, :, s]), bits(ll0[:, :, s])), s
         else:
-            assert ly > 0 and lr > 0, s
             assert np.all(close(ll1[:, :, s], ll0[:, :, s])), s
+            assert np.array_equal(bits(ll1[out[:, s], :, s]), bits(ll0[out[:, s], :, s])), s
+    st = b.table_stats()
+    assert st["n_samples_without_tables"] == 9 and st["n_cells_without_tables"] == 9 * E and st["cold_list_overflow"] == 0, st
+    assert st["n_cold_cells"] == out[:, ~notab].sum(), st
     assert r[0]["nerr"] == r[1]["nerr"] and r[0]["nerr"] > 0
     assert np.array_equal(r[0]["path"], r[1]["path"]) and np.array_equal(r[0]["calls"], r[1]["calls"])
     for m in (0, 1):
         r[m]["batch"].close()
     plan.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_every_sample_without_tables(edlib, mode):
+    """a batch none of whose samples the tables serve (phi >= 1): the strict pass walks all of it -- mode 0's bits, no list entries, no re-scan"""
+    E, S = 2600, 80
+    chrom_off, start, end = synth.exon_design(E, 3, 14)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 14, n_segments=2, mean_depth=40.0)
+    phi = np.full(S, 1.25)
+    plan = ed.Plan(chrom_off, start, end)
+    for overlap in (0, 1):
+        r = {}
+        for key, m in ((0, 0), (1, mode)):
+            b = ed.Batch(plan, S); b.set_viterbi_overlap(overlap)
+            if m:
+                b.set_emit_mode(m)
+            b.run(test, ref, phi, p)
+            r[key] = dict(ll=b.loglik(), path=b.path(), calls=b.calls(), nerr=b.n_gsl_errors(), batch=b)
+        assert np.array_equal(bits(r[1]["ll"]), bits(r[0]["ll"]))
+        st = r[1]["batch"].table_stats()
+        assert st == {"n_cold_cells": 0, "n_samples_without_tables": S, "cold_list_overflow": 0, "n_cells_without_tables": S * E}, st
+        assert r[0]["nerr"] == r[1]["nerr"]
+        assert np.array_equal(r[0]["path"], r[1]["path"]) and np.array_equal(r[0]["calls"], r[1]["calls"])
+        for m in (0, 1):
+            r[m]["batch"].close()
+    plan.close()
+
+
+def aggregate_reference_batch(E, S, seed, depth=100.0, kmin=20, kmax=32):
+    """the reference's workflow in small: a cohort's counts; every sample's reference is the sum of 20 - 32 OTHER samples of the cohort
+    (vignette/vignette.Rnw:390-402), i.e. deep references, expected ~ 1 / (k + 1) = 0.03 - 0.05"""
+    chrom_off, start, end = synth.exon_design(E, 4, seed)
+    cohort, _, _, _, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=3, mean_depth=depth)
+    rng = np.random.default_rng(seed)
+    ref = np.zeros_like(cohort)
+    for s in range(S):
+        k = int(rng.integers(kmin, kmax + 1))
+        others = rng.choice(np.delete(np.arange(S), s), size=min(k, S - 1), replace=False)
+        ref[:, s] = cohort[:, others].sum(axis=1)
+    return chrom_off, start, end, cohort, ref
+
+
+@pytest.mark.parametrize("mode,layout", [(2, 1), (2, 0), (1, 0)])
+def test_deep_aggregate_references(edlib, oracle, mode, layout):
+    """VERDICT r4 item 1: references that are 20 - 32-sample aggregates (the reference's real usage).  Dispersion fitted on the device;
+    >= 95 % of the samples on tables, the strict lists a small fraction of the cells, every log-likelihood within 1e-10 RELATIVE of the
+    reference's arithmetic (no absolute floor), 0 discordant Viterbi states / call rows against it."""
+    E, S = 12_000, 72
+    chrom_off, start, end, test, ref = aggregate_reference_batch(E, S, 31)
+    test[:25, :] = 0; ref[:25, :] = 0            # exons without reads
+    test[40:60, :] = 0                           # obs = 0 over a deep reference: the smallest values of a column
+    plan = ed.Plan(chrom_off, start, end)
+    b = ed.Batch(plan, S)
+    b.set_emit_mode(mode); b.set_counts_layout(layout)
+    t_in, r_in = (np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)) if layout else (test, ref)
+    dt, dr = ed.DeviceArray(t_in), ed.DeviceArray(r_in)
+    dphi, dexp = ed.DeviceArray(np.zeros(S)), ed.DeviceArray(np.zeros(S))
+    b.fit(dt, dr, dphi, dexp)
+    b.run(dt, dr, dphi, dexp)
+    phi, p = np.asarray(dphi.to_host()), np.asarray(dexp.to_host())
+    assert np.all((p > 0.015) & (p < 0.1)) and np.median(p) < 0.05, (p.min(), p.max())
+    st = b.table_stats()
+    out, notab = not_served(b, test, ref)
+    assert notab.sum() <= S // 20, (notab.sum(), st)
+    assert st["n_samples_without_tables"] == notab.sum() and st["cold_list_overflow"] == 0, st
+    assert st["n_cold_cells"] == out[:, ~notab].sum() <= E * S // 200, st
+    ll, path, calls = b.loglik(), b.path(), b.calls()
+    n_beyond = n_floor = n_states = n_rows = 0
+    worst = 0.0
+    for s in range(S):
+        ell, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.LIBM)
+        got = ll[:, :, s]
+        n_beyond += int(np.sum(~close_rel(got, ell)))
+        n_floor += int(np.sum(close(got, ell) & ~close_rel(got, ell)))
+        nz = np.isfinite(ell) & (ell != 0)
+        worst = max(worst, float(np.max(np.abs(got[nz] - ell[nz]) / np.abs(ell[nz]))))
+        epath, ecalls = oracle.callcnvs(ell, chrom_off, start, end)
+        n_states += int(np.sum(path[:, s].astype(np.int8) != epath))
+        mine = calls[calls["sample"] == s]
+        gotc = {tuple(int(v) for v in row) for row in zip(mine["start_exon"] + 1, mine["end_exon"] + 1, mine["type"], mine["nexons"])}
+        n_rows += len(gotc ^ {tuple(int(v) for v in row[:4]) for row in ecalls})
+    assert n_beyond == 0 and n_floor == 0, (n_beyond, n_floor, worst)
+    assert n_states == 0 and n_rows == 0, (n_states, n_rows)
+    assert worst < 2e-11, worst
+    b.close(); plan.close()
 
 
 @pytest.mark.parametrize("mode", MODES)

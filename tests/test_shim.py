@@ -131,7 +131,7 @@ def test_registration_is_the_references(shim):
     next to them the three cohort-level entries of this library."""
     names = [shim.R.minir_registered_name(i).decode() for i in range(shim.R.minir_n_registered())]
     assert names[:2] == ["C_hmm", "get_loglike_matrix"]
-    assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5, "ed_call_cnvs_batch": 15,
+    assert {k: v[0] for k, v in shim.entries.items()} == {"C_hmm": 6, "get_loglike_matrix": 5, "ed_call_cnvs_batch": 16,
                                                           "ed_fit_betabin_batch": 3, "ed_select_reference_set": 4, "ed_cohort_reference_sets": 4}
     assert shim.R.minir_dynamic_symbols() == 0
     for name in ("C_hmm", "get_loglike_matrix"):
@@ -260,7 +260,7 @@ def test_call_cnvs_batch_through_sexp_equals_ctypes_path(shim, edlib, given, sla
     res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
                                   shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.real(phi) if given else shim.nil,
                                   shim.real(p) if given else shim.nil, shim.real([1.0]), shim.integer([slab]), shim.integer([1]), shim.integer([mode]),
-                                  shim.integer([1]), shim.integer([emit]))
+                                  shim.integer([1]), shim.integer([emit]), shim.nil)
     assert res is not None and err == "" and out == ""
     got = shim.as_list(res)
     assert list(got) == ["sample", "start.p", "end.p", "type", "nexons", "BF", "reads.expected", "reads.observed", "reads.ratio", "phi",
@@ -314,7 +314,7 @@ def test_call_cnvs_batch_leaves_nothing_behind_when_r_unwinds(shim, edlib):
     chrom_off, start, end, test, ref, p, phi = _cohort_case(E=3000, S=40)
     args = lambda: (shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start), shim.integer(end), shim.real([1e-4]),
                     shim.real([50000.0]), shim.nil, shim.nil, shim.real([1.0]), shim.integer([40]), shim.integer([1]), shim.integer([0]),
-                    shim.integer([1]), shim.integer([0]))
+                    shim.integer([1]), shim.integer([0]), shim.nil)
     shim.R.minir_run_finalizers()
     res, out, err = shim.dot_call("ed_call_cnvs_batch", *args())
     assert res is not None and err == ""
@@ -332,6 +332,40 @@ def test_call_cnvs_batch_leaves_nothing_behind_when_r_unwinds(shim, edlib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("emit,B", [(2, 1), (0, 1), (0, 3)])
+def test_call_cnvs_batch_over_several_devices(shim, edlib, emit, B):
+    """.Call("ed_call_cnvs_batch", ..., devices = c(0L, 0L)): the cohort's columns dealt to two pipelines, each driven by its own host thread
+    (on this box both on device 0; on a node `devices = NULL` takes every visible GPU), call tables merged in column order -- the very
+    list the single-device call returns, bit for bit (same slabs: the fit's start values are shared work of a slab)."""
+    chrom_off, start, end, test, ref, p, phi = _cohort_case(S=200)
+    E, S = test.shape
+    slab = 50                        # 4 slabs of the 200 columns: 2 per device
+    assert S == 4 * slab
+    def call(devs):
+        res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
+                                      shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.nil, shim.nil, shim.real([1.0]),
+                                      shim.integer([slab]), shim.integer([1]), shim.integer([0]), shim.integer([B]), shim.integer([emit]),
+                                      shim.integer(devs) if devs is not None else shim.nil)
+        assert res is not None and err == "" and out == "", err
+        return shim.as_list(res)
+    one, two, three = call([0]), call([0, 0]), call([0, 0, 0])
+    for got in (two, three):
+        for k in one:
+            a, b = one[k], got[k]
+            if a is None:
+                assert b is None, k
+            else:
+                assert np.asarray(a).tobytes() == np.asarray(b).tobytes(), k
+    assert len(one["sample"]) > 50 and np.all(np.diff(one["sample"]) >= 0)
+    # a device that does not exist is an R error with the library's message
+    res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
+                                  shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.nil, shim.nil, shim.real([1.0]),
+                                  shim.integer([slab]), shim.integer([0]), shim.integer([0]), shim.integer([B]), shim.integer([emit]), shim.integer([0, 99]))
+    assert res is None and "device 99" in err
+    assert shim.R.minir_protect_balance() == 0
+
+
+@pytest.mark.gpu
 def test_call_cnvs_batch_with_phi_bins_through_sexp(shim, edlib):
     """the reference's phi.bins argument (R/class_definition.R:86, :120-147) through .Call("ed_call_cnvs_batch", ..., phi.bins = 3):
     phi.estimates per depth level and complete.bins come back as matrices, `phi` is NA, and calls / decoration / path are those of
@@ -341,7 +375,7 @@ def test_call_cnvs_batch_with_phi_bins_through_sexp(shim, edlib):
     B = 3
     res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
                                   shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.nil, shim.nil, shim.real([1.0]),
-                                  shim.integer([150]), shim.integer([1]), shim.integer([0]), shim.integer([B]), shim.integer([0]))
+                                  shim.integer([150]), shim.integer([1]), shim.integer([0]), shim.integer([B]), shim.integer([0]), shim.nil)
     assert res is not None and err == "" and out == ""
     got = shim.as_list(res)
     phib = np.asarray(got["phi.bins"]).reshape(S, B).T            # B x S, column-major
@@ -361,7 +395,7 @@ def test_call_cnvs_batch_with_phi_bins_through_sexp(shim, edlib):
     # parameters cannot be given in this mode: an R error before any device work
     res, out, err = shim.dot_call("ed_call_cnvs_batch", shim.int_matrix(test), shim.int_matrix(ref), shim.integer(chrom_off), shim.integer(start),
                                   shim.integer(end), shim.real([1e-4]), shim.real([50000.0]), shim.real(phi), shim.real(p), shim.real([1.0]),
-                                  shim.integer([150]), shim.integer([0]), shim.integer([0]), shim.integer([B]), shim.integer([0]))
+                                  shim.integer([150]), shim.integer([0]), shim.integer([0]), shim.integer([B]), shim.integer([0]), shim.nil)
     assert res is None and "phi.bins" in err
     assert shim.R.minir_protect_balance() == 0
 
