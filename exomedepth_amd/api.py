@@ -488,7 +488,7 @@ class Batch:
         return dict(zip(self.TABLE_STATS, (int(x) for x in v)))
 
     def table_dims(self, sample):
-        """(Ly, Lr, Tm1, reason) of one sample in the last run (ed_batch_copy_table_dims)"""
+        """(Ly, Lr, Tm1, w) of one sample in the last run (ed_batch_copy_table_dims): w = N0 of the ref = 0 rule, or the reason when Ly = 0"""
         d = (C.c_int32 * 4)()
         check(lib().ed_batch_copy_table_dims(self.handle, int(sample), d))
         return tuple(int(x) for x in d)

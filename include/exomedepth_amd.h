@@ -313,10 +313,12 @@ int ed_batch_verify_emissions_tol(ed_batch* batch, const int32_t* d_test, const 
                                   int64_t* n_beyond, double* max_rel, double* max_abs, ed_emit_mismatch* first, int64_t cap);
 /* Table-mode diagnostics: one sample's tables as the last run built them -- dims = (Ly, Lr); entries [2 (Ly + Lr)][3]: the obs
  * table (Ly entries), the ref table (Lr), the tot table (Ly + Lr), each entry (deletion, normal, duplication).
- * ed_batch_copy_table_dims: (Ly, Lr, Tm1, reason) of a sample -- a cell is served by the tables when obs < Ly, ref < Lr and not
- * 0 < tot <= Tm1 (few reads under a nearly binomial model: the REFERENCE's value is too noisy there for a 1e-10 relative comparison);
- * reason != 0 = the sample has no tables (1 GSL error in a per-sample constant, 2 shape parameters not positive normal numbers,
- * 3 ill-conditioned at any useful table length, 4 too many few-read cells) and is evaluated whole by the strict arithmetic.
+ * ed_batch_copy_table_dims: (Ly, Lr, Tm1, w) of a sample -- a cell is served by the tables when obs < Ly, ref < Lr, not
+ * 0 < tot <= Tm1 (few reads under a nearly binomial model) and not (ref = 0 and obs >= w) (the reference rounds its second argument
+ * (a2 + total) - observed at the size of the total: with a2 << 1 its own value is off by more than the bar) -- in both cases the
+ * REFERENCE's value is too noisy for a 1e-10 relative comparison, so the cell takes the reference's arithmetic.  Ly = 0: the sample
+ * has no tables and w is the reason (1 GSL error in a per-sample constant, 2 shape parameters not positive normal numbers,
+ * 3 ill-conditioned at any useful table length, 4 too many few-read cells); it is evaluated whole by the strict arithmetic.
  * ed_batch_table_stats: what the last run left to the strict arithmetic -- out[0] cells on the strict lists (all launch groups),
  * out[1] samples without tables, out[2] launch groups whose lists ran out (every cell looked at again), out[3] cells of the
  * samples without tables.  ed_batch_n_cold_cells = out[0]. */

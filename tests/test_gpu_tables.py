@@ -35,17 +35,17 @@ MODES = (1, 2)     # 1: exon-major tiles, tables through the caches; 2: sample-m
 
 
 def not_served(b, test, ref):
-    """[E][S] mask of the cells the tables of the last run do not serve (ed_batch_copy_table_dims: outside (Ly, Lr), or 0 < tot <= Tm1),
+    """[E][S] mask of the cells the tables of the last run do not serve (ed_batch_copy_table_dims: outside (Ly, Lr), 0 < tot <= Tm1, or ref = 0 with obs >= N0),
     and the [S] mask of samples without tables"""
     E, S = test.shape
     out = np.zeros((E, S), dtype=bool)
     notab = np.zeros(S, dtype=bool)
     for s in range(S):
-        ly, lr, tm1, reason = b.table_dims(s)
+        ly, lr, tm1, w = b.table_dims(s)
         t, r = test[:, s].astype(np.int64), ref[:, s].astype(np.int64)
-        out[:, s] = ~((t >= 0) & (t < ly) & (r >= 0) & (r < lr)) | ((t + r >= 1) & (t + r <= tm1))
+        out[:, s] = ~((t >= 0) & (t < ly) & (r >= 0) & (r < lr)) | ((t + r >= 1) & (t + r <= tm1)) | ((r == 0) & (t >= w))
         notab[s] = ly == 0
-        assert (reason != 0) == (ly == 0)
+        assert w in (1, 2, 3, 4) if ly == 0 else w >= 1
     return out, notab
 
 
@@ -217,6 +217,38 @@ def test_every_sample_without_tables(edlib, mode):
         assert np.array_equal(r[0]["path"], r[1]["path"]) and np.array_equal(r[0]["calls"], r[1]["calls"])
         for m in (0, 1):
             r[m]["batch"].close()
+    plan.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_reference_rounds_its_second_argument(edlib, oracle, mode):
+    """expected close to 1 (the test sample far deeper than its reference) makes a2 << 1; the reference forms its second argument as
+    (a2 + total) - observed (src/CNV_estimate.cpp:49), rounded at the size of the total -- for ref = 0 its own value is then 2e-10 away
+    from the exact one (found by tools/fuzz_tables.py: phi 0.1988, expected 0.99907, (obs, ref) = (24, 0), duplication state), while the
+    tables are exact to 2e-12.  Parity is measured against the reference: those cells take its arithmetic (the N0 of table_dims)."""
+    rng = np.random.default_rng(8)
+    E, S = 1200, 12
+    chrom_off, start, end = synth.exon_design(E, 2, 8)
+    p = np.array([0.9990708643096986] * 4 + [0.998, 0.9995, 0.99, 0.97] * 2)
+    phi = np.array([0.19884239345741983] * 4 + [0.05, 0.3, 0.01, 0.1, 0.02, 0.15, 0.2, 0.005])
+    tot = rng.poisson(np.exp(rng.uniform(0, np.log(400.0), (E, S)))).astype(np.int64)
+    ref = rng.binomial(tot, (1 - p)[None, :]).astype(np.int32)
+    test = (tot - ref).astype(np.int32)
+    test[0, 0] = 24; ref[0, 0] = 0
+    plan = ed.Plan(chrom_off, start, end)
+    r = run_modes(plan, S, test, ref, phi, p, mode)
+    b = r[1]["batch"]
+    out, notab = not_served(b, test, ref)
+    assert not notab[:4].any() and out[0, 0] and b.table_dims(0)[3] <= 24
+    for s in range(S):
+        ell, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.LIBM)
+        assert np.all(close_rel(r[1]["ll"][:, :, s], ell)), (s, phi[s], p[s])
+    assert np.all(close_rel(r[1]["ll"], r[0]["ll"]))
+    sel = np.broadcast_to(out[:, None, :], r[0]["ll"].shape)
+    assert np.array_equal(bits(r[1]["ll"][sel]), bits(r[0]["ll"][sel]))
+    assert np.array_equal(r[0]["path"], r[1]["path"]) and np.array_equal(r[0]["calls"], r[1]["calls"])
+    for m in (0, 1):
+        r[m]["batch"].close()
     plan.close()
 
 

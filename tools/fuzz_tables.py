@@ -4,8 +4,11 @@ widths, empty chromosomes, depths from 2 to 3000 reads per exon, dispersions and
 serve, tumour mixtures, negative counts, tiny table caps (most cells through the strict list / the full-scan fallback), both count
 layouts, overlap groups on and off, repeated runs on one batch object.
     python tools/fuzz_tables.py [seconds] [seed]
-Asserts: every log-likelihood within 1e-10 relative / 1e-12 absolute of strict mode's (NaN for NaN); cells the tables do not serve
-bit-identical; the same GSL error counts; and reports the Viterbi states / call rows that differ (expected: 0)."""
+Asserts: every log-likelihood within 1e-10 RELATIVE of strict mode's (NaN for NaN, equal values pass; no absolute floor -- the values
+that would have needed the old 1e-12 floor are counted and must be 0); cells the tables do not serve (outside (Ly, Lr), under the
+few-reads rule, or of samples without tables) bit-identical; the same GSL error counts; and reports the Viterbi states / call rows
+that differ (expected: 0).  A third of the cases are the reference's workflow in small: references that are sums of 8 - 32 other
+samples of the cohort (deep, expected 0.03 - 0.1)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,11 +24,16 @@ bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
 def close(got, want):
+    return (np.isnan(got) & np.isnan(want)) | (got == want) | (np.abs(got - want) <= 1e-10 * np.abs(want))
+
+
+def close_floor(got, want):
     return (np.isnan(got) & np.isnan(want)) | (got == want) | (np.abs(got - want) <= np.maximum(1e-12, 1e-10 * np.abs(want)))
 
 
 t0 = time.time()
-n_cases = n_cells = n_disc_states = n_disc_calls = n_oracle_cols = 0
+n_cases = n_cells = n_disc_states = n_disc_calls = n_oracle_cols = n_cold = n_notab = n_samples = n_floor = 0
+worst_a12 = 0.0
 worst = 0.0
 worst_at = None
 while time.time() - t0 < budget:
@@ -41,7 +49,14 @@ while time.time() - t0 < budget:
         C += 1
     depth = float(np.exp(rng.uniform(np.log(2.0), np.log(3000.0))))
     test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=2, mean_depth=depth)
-    if rng.random() < 0.3:
+    if rng.random() < 0.33 and S >= 9:                  # aggregate references: sums of other samples of the cohort
+        agg = np.zeros_like(test)
+        for j in range(S):
+            k = int(rng.integers(8, min(33, S)))
+            agg[:, j] = test[:, rng.choice(np.delete(np.arange(S), j), size=k, replace=False)].sum(axis=1)
+            p[j] = float(test[:, j].sum() + 0.5) / float(test[:, j].sum() + agg[:, j].sum() + 1.0)
+        ref = np.minimum(agg, 2**30).astype(np.int32)
+    elif rng.random() < 0.3:
         test, ref, p = ref.copy(), test.copy(), 1.0 - p
     if rng.random() < 0.5:
         dead = rng.random(test.shape) < 0.2
@@ -96,9 +111,14 @@ while time.time() - t0 < budget:
                 e_, st_, s_ = (int(v) for v in np.unravel_index(int(np.argmax(rel)), rel.shape))
                 worst_at = dict(mode=mode, phi=float(phi[s_]), p=float(p[s_]), state=st_, obs=int(test[e_, s_]), ref=int(ref[e_, s_]), strict=float(ll0[e_, st_, s_]),
                                 mixture=mixture, a12=(1.0 - float(phi[s_])) / float(phi[s_]))
-        for s in range(S):                          # samples without tables: strict bits
-            if b.emit_tables(s)[0] == 0:
-                assert np.array_equal(bits(ll[:, :, s]), bits(ll0[:, :, s])), ("strict bits", mode, E, S, seed, s)
+        n_floor += int(np.sum(close_floor(ll, ll0) & ~ok))
+        st = b.table_stats()
+        n_cold += st["n_cold_cells"]; n_notab += st["n_samples_without_tables"]; n_samples += S
+        for s in range(S):                          # what the tables do not serve: strict bits
+            ly, lr, tm1, w = b.table_dims(s)
+            t64, r64 = test[:, s].astype(np.int64), ref[:, s].astype(np.int64)
+            out = ~((t64 >= 0) & (t64 < ly) & (r64 >= 0) & (r64 < lr)) | ((t64 + r64 >= 1) & (t64 + r64 <= tm1)) | ((r64 == 0) & (t64 >= w))
+            assert np.array_equal(bits(ll[out, :, s]), bits(ll0[out, :, s])), ("strict bits", mode, E, S, seed, s, ly, lr, tm1, w)
         assert b.n_gsl_errors() == nerr0, ("nerr", mode, E, S, seed)
         d = int(np.sum(path != path0))
         n_disc_states += d
@@ -109,13 +129,18 @@ while time.time() - t0 < budget:
             if b.emit_tables(int(s))[0] == 0:
                 continue
             ell, _ = eo.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], mixture, eo.LIBM)
-            assert close(ll[:, :, s], ell).all(), ("libm", mode, E, S, seed, int(s), phi[s], p[s])
+            okl = close(ll[:, :, s], ell)
+            if not okl.all():
+                for e, st_ in np.argwhere(~okl)[:8]:
+                    print("  libm: exon", e, "state", st_, "sample", s, "obs", test[e, s], "ref", ref[e, s], "phi", phi[s], "p", p[s], "got %r" % ll[e, st_, s], "libm %r" % ell[e, st_])
+            assert okl.all(), ("libm", mode, E, S, seed, int(s), phi[s], p[s])
             n_oracle_cols += 1
         b.close()
         n_cells += E * S
     plan.close()
     n_cases += 1
-print("fuzz_tables ok: %d cases, %d cells in table modes, max relative difference from strict mode %.2e, %d discordant Viterbi states, "
-      "%d discordant call rows, %d columns against the checker's libm flavour, %.0f s"
-      % (n_cases, n_cells, worst, n_disc_states, n_disc_calls, n_oracle_cols, time.time() - t0))
+print("fuzz_tables ok: %d cases, %d cells in table modes, max relative difference from strict mode %.2e (bar 1e-10, no absolute floor; %d values would have "
+      "needed the 1e-12 floor), %d discordant Viterbi states, %d discordant call rows, %d columns against the checker's libm flavour, "
+      "%d cells on the strict lists, %d of %d samples without tables, %.0f s"
+      % (n_cases, n_cells, worst, n_floor, n_disc_states, n_disc_calls, n_oracle_cols, n_cold, n_notab, n_samples, time.time() - t0))
 print("  the largest difference:", worst_at)
