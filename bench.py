@@ -415,6 +415,59 @@ def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps, opts={}):
             "unit": "exons*samples/s", **res}
 
 
+def multi_device_main(args):
+    """--driver multi-device: N devices from one process (ed_multi_*, csrc/edmulti.inc).  Weak scaling: every device gets --samples columns.
+    The entry is the host-level one (the .Call boundary hands over host matrices), so a step here INCLUDES the upload of its counts from
+    pinned host memory (uint16 on the link, R's column-major layout) and the collection of the call table: it is comparable with
+    `h2d.pinned` of the default line, not with its device-resident `value`."""
+    import exomedepth_amd as ed
+    from exomedepth_amd import _build, synth
+    if not os.path.exists(_build.LIB):
+        _build.build()
+    N = args.gpus
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(N))
+    assert len(devices) == N, "--devices must name --gpus devices"
+    E, S, C = args.exons, args.samples, args.chroms
+    chrom_off, start, end = synth.exon_design(E, C, seed=20250620)
+    import torch
+    dev = torch.device("cuda", devices[0])
+    test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=20250620 + 3, mean_depth=args.depth)
+    th, rh = test.t().contiguous().cpu().numpy(), ref.t().contiguous().cpu().numpy()      # [S][E]: R's column-major exons x samples
+    assert th.max() < 65536 and rh.max() < 65536
+    del test, ref
+    torch.cuda.empty_cache()
+    pt, pr = ed.PinnedArray((S * N, E), np.uint16), ed.PinnedArray((S * N, E), np.uint16)
+    for i in range(N):                              # every device's share: the same synthetic slab (weak scaling)
+        pt.array[i * S:(i + 1) * S] = th; pr.array[i * S:(i + 1) * S] = rh
+    opts = {"emit_mode": 2, "counts_layout": 1} if args.emit_mode == "tables" else {}
+    slab = min(S, 512)                              # two slabs per device and step: upload of the second under the compute of the first
+    m = ed.MultiDevice(chrom_off, start, end, slab, devices=devices, **opts)
+    par = {} if args.fit else {"phi": np.tile(phi.cpu().numpy(), N), "expected": np.tile(p.cpu().numpy(), N)}
+    for _ in range(max(1, args.warmup)):
+        res = m.run_host(pt.array, pr.array, 1, **par)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = m.run_host(pt.array, pr.array, 1, **par)
+    el = time.perf_counter() - t0
+    n_calls = len(res["calls"])
+    per_dev = [int(np.sum((res["calls"]["sample"] >= b) & (res["calls"]["sample"] < e))) for _, b, e, _ in res["shares"]]
+    out = {"metric": "exons*samples/s through betabinom emissions + Viterbi" + (" + dispersion fit" if args.fit else ""),
+           "value": float(E) * S * N * args.steps / el, "unit": "exons*samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[2] geometry per device: %d exons x %d samples, %d chromosomes, phi %s; ONE process, %d device(s) %s, "
+                                  "host-resident counts (pinned, uint16 on the link, [samples][exons]) -> ed_multi_run_host -> merged call table"
+                                  % (E, S, C, "fitted on device" if args.fit else "given", N, devices),
+                      "exons": E, "samples_per_gpu": S, "samples_total": S * N, "fit": bool(args.fit), "emit_mode": args.emit_mode, "driver": "multi-device (ed_multi_run_host: one host thread per device, no collective)",
+                      "slab_samples": slab, "devices": devices},
+           "includes_h2d": True, "bytes_on_the_link_per_step": 2.0 * 2 * E * S * N,
+           "shares": [{"device": d, "columns": [b, e], "thread_seconds_last_step": sec} for d, b, e, sec in res["shares"]],
+           "n_calls": n_calls, "n_calls_per_device": per_dev, "table_stats": res["table_stats"], "n_unconverged": res["n_unconverged"],
+           "note": "host-fed: comparable with h2d.pinned of the default line (N = 1), not with its device-resident value; no roofline / cpu_baseline "
+                   "on this line (see the default line)"}
+    print(json.dumps(out))
+    m.close(); pt.free(); pr.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -457,9 +510,12 @@ def main():
     ap.add_argument("--pretouch-streams", type=int, default=0, help="(diagnostic) use that many unrelated streams before the pipeline's streams are first used")
     ap.add_argument("--hw-queues", type=int, default=0, help="(diagnostic) GPU_MAX_HW_QUEUES for this process unless the environment already sets it "
                     "(0, default = leave the runtime alone: the cohort pipeline gives its streams hardware queues of their own)")
-    ap.add_argument("--driver", default="cohort", choices=["cohort", "python"], help="cohort (default): the steps are submitted to the "
+    ap.add_argument("--driver", default="cohort", choices=["cohort", "python", "multi-device"], help="cohort (default): the steps are submitted to the "
                     "library's cohort pipeline (ed_cohort_*: its own streams, batch rotation, event-ordered stages); python: round 2's "
-                    "orchestration of two batch objects with torch streams (kept for comparison)")
+                    "orchestration of two batch objects with torch streams (kept for comparison); multi-device: ONE process drives --gpus N devices "
+                    "through ed_multi_run_host (one host thread per device, no process group) -- the second N > 1 path, what the R-level "
+                    ".Call entry runs on; launched as a plain `python bench.py --gpus N --driver multi-device`, NOT under torch.distributed.run")
+    ap.add_argument("--devices", default="", help="--driver multi-device: comma-separated device ordinals (default 0..N-1; '0,0' = two pipelines on one GPU)")
     ap.add_argument("--split", type=float, default=-1.0, help="cohort driver: fraction of a slab's emission launch after which the next slab's fit "
                     "is issued (-1 = the library's default)")
     ap.add_argument("--own-queues", type=int, default=-1, help="cohort driver: 1 = every stream of the pipeline gets a hardware queue of its own, "
@@ -495,6 +551,9 @@ def main():
     # Must be in the environment before the HIP runtime starts, i.e. before torch is imported.
     if args.hw_queues > 0:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues))
+
+    if args.driver == "multi-device":
+        return multi_device_main(args)
 
     import torch
     import torch.distributed as dist

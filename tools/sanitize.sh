@@ -5,7 +5,7 @@
 # left alone (-fno-gpu-sanitize).  Python is not instrumented: the sanitizer runtime is preloaded.
 #   tools/sanitize.sh cpu  [log]     the -m "not gpu" tests that load the library / the shim (runs without a GPU)
 #   tools/sanitize.sh gpu  [log]     + tests/test_gpu_cohort.py, tests/test_gpu_refcohort.py, tests/test_shim.py -m gpu on the GPU box
-#   tools/sanitize.sh tsan [log]     tests/test_gpu_cohort.py under ThreadSanitizer
+#   tools/sanitize.sh tsan [log]     tests/test_gpu_cohort.py, test_gpu_refcohort.py, test_gpu_multidevice.py (one host thread per device) under ThreadSanitizer
 set -u
 MODE=${1:-cpu}; LOG=${2:-gpurun_out/sanitize_$MODE.log}
 mkdir -p $(dirname $LOG)
@@ -29,8 +29,8 @@ python -c "from exomedepth_amd import _build; print(_build.build_variant('$VAR')
 export ED_LIB_VARIANT=$VAR ED_SHIM_CC=$CLANG ED_SHIM_CFLAGS="$SHIMF"
 case $MODE in
   cpu)  T="tests/test_abi.py tests/test_host_logic.py tests/test_shim.py"; M='not gpu' ;;
-  gpu)  T="tests/test_abi.py tests/test_host_logic.py tests/test_shim.py tests/test_gpu_cohort.py tests/test_gpu_refcohort.py tests/test_gpu_tables.py"; M='gpu or not gpu' ;;
-  tsan) T="tests/test_gpu_cohort.py tests/test_gpu_refcohort.py"; M='gpu' ;;
+  gpu)  T="tests/test_abi.py tests/test_host_logic.py tests/test_shim.py tests/test_gpu_cohort.py tests/test_gpu_refcohort.py tests/test_gpu_tables.py tests/test_gpu_multidevice.py"; M='gpu or not gpu' ;;
+  tsan) T="tests/test_gpu_cohort.py tests/test_gpu_refcohort.py tests/test_gpu_multidevice.py"; M='gpu' ;;
 esac
 echo "== $MODE: LD_PRELOAD=$PRE python -m pytest $T -m \"$M\"" >> $LOG
 # (deselected: the one test that generates its data with torch on the GPU -- torch's own HIP initialisation does not find the device
