@@ -171,7 +171,7 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
     cols = sorted(set(int(c) for c in np.linspace(0, S - 1, k).round()))
     out = {"columns": 0, "loglik_values": 0, "loglik_bit_mismatches": 0, "discordant_states": 0, "discordant_calls": 0, "slabs": 0}
     if tables:   # emit mode 1: tolerance parity against the LIBM flavour (= the reference's arithmetic), 1e-10 relative / 1e-12 absolute
-        out = {"columns": 0, "loglik_values": 0, "loglik_beyond_1e-10": 0, "loglik_max_rel_diff": 0.0, "discordant_states": 0,
+        out = {"columns": 0, "loglik_values": 0, "loglik_beyond_1e-10": 0, "loglik_needed_abs_floor": 0, "loglik_max_rel_diff": 0.0, "discordant_states": 0,
                "discordant_calls": 0, "slabs": 0}
     slabs = []
     if co is not None:
@@ -198,7 +198,10 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
             out["loglik_values"] += int(got.size)
             if tables:
                 d = np.abs(got - ell)
-                out["loglik_beyond_1e-10"] += int(np.sum(~((d <= np.maximum(1e-12, 1e-10 * np.abs(ell))) | (np.isnan(got) & np.isnan(ell)))))
+                same = (got == ell) | (np.isnan(got) & np.isnan(ell))
+                rel_ok = same | (d <= 1e-10 * np.abs(ell))          # north_star's bar as written: relative, no floor
+                out["loglik_beyond_1e-10"] += int(np.sum(~rel_ok))
+                out["loglik_needed_abs_floor"] += int(np.sum(~rel_ok & (d <= 1e-12)))      # (what a 1e-12 absolute floor would have let through)
                 nz = np.isfinite(ell) & (ell != 0)
                 if nz.any():
                     out["loglik_max_rel_diff"] = max(out["loglik_max_rel_diff"], float(np.max(d[nz] / np.abs(ell[nz]))))
@@ -213,7 +216,7 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
             out["columns"] += 1
     out["what"] = ("%d columns x %d slab(s) in flight after the timed region: %s, Viterbi "
                    "states and call rows vs the checker's Viterbi, given the (phi, expected) the device used"
-                   % (len(cols), len(slabs), "likelihood values vs the checker's LIBM flavour (the reference's arithmetic), 1e-10 relative / 1e-12 absolute"
+                   % (len(cols), len(slabs), "likelihood values vs the checker's LIBM flavour (the reference's arithmetic), 1e-10 RELATIVE with no absolute floor (loglik_needed_abs_floor: values among those beyond it that a 1e-12 floor would have let through)"
                       if tables else "likelihood bits vs the checker's portable flavour"))
     return out
 
