@@ -78,6 +78,19 @@ def pmc_figures(meta, kernel, cells_per_step, kernel_cells_per_s):
         out["traffic_bytes_per_launch"] = (ff * f + w) * 1024.0
         out["traffic_bytes_per_step"] = (ff * f + w) * 1024.0 * n / runs(fe, "FETCH_SIZE")
         out["launches_per_step_profiled"] = n / runs(fe, "FETCH_SIZE")
+    # the whole step: every kernel of the library in the FETCH / WRITE passes, per batch run.  x2 on the kernels that stream with 16-byte
+    # loads (the guide's gfx950 correction), x1 on the others (4-byte-per-lane / scattered reads: calibrated on k_emit_tab_sm's known bytes)
+    WIDE = ("k_viterbi_sm", "k_viterbi", "k_fit_hist_sm")
+    if fe and wr:
+        per_kernel = {}
+        for (kn, cn), (mean, n) in fe.items():
+            if cn != "FETCH_SIZE" or (kn, "WRITE_SIZE") not in wr:
+                continue
+            ff = 2.0 if kn.split("::")[-1] in WIDE else 1.0
+            per_kernel[kn] = (ff * mean + wr[(kn, "WRITE_SIZE")][0]) * 1024.0 * n / runs(fe, "FETCH_SIZE")
+        out["step_traffic_bytes"] = sum(per_kernel.values())
+        out["step_traffic_by_kernel_GB"] = {k: round(v / 1e9, 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]) if v > 1e7}
+        out["step_traffic_fetch_x2_kernels"] = [k for k in per_kernel if k.split("::")[-1] in WIDE]
     if (kernel, "SQ_INSTS_VALU") in sq and (kernel, "GRBM_GUI_ACTIVE") in gr:
         insts, n = sq[(kernel, "SQ_INSTS_VALU")]
         per_cell = insts * n / runs(sq, "SQ_INSTS_VALU") / (cells_per_step / 64.0)          # lane-instructions per cell
@@ -878,6 +891,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (pmc["profile"] + "_pmc_FETCH_SIZE/WRITE_SIZE.csv") if traffic is not None else why_not,
+                         "step_traffic_bytes": (pmc.get("step_traffic_bytes") if pmc else None),
+                         "step_traffic_over_algorithmic": (pmc["step_traffic_bytes"] / (ALGO_BYTES_PER_CELL * float(E) * S) if pmc and pmc.get("step_traffic_bytes") else None),
+                         "step_traffic_GBps": (pmc["step_traffic_bytes"] / (elapsed / args.steps) / 1e9 if pmc and pmc.get("step_traffic_bytes") else None),
                          "algorithmic_bytes_per_cell": ALGO_BYTES_PER_CELL, "launches_per_step": n_launch,
                          "kernel_ms": stage_ms["emissions"] / n_launch, "kernel_ms_per_step": stage_ms["emissions"],
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * E * S / n_launch,
