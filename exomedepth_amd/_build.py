@@ -66,6 +66,8 @@ def build(force=False, verbose=False):
 
 # Diagnostic variants of the library (same sources, different code generation); never loaded by the package itself.
 VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
+            # k_viterbi_sm without its raised wave priority (round 5 A/B: tools/ab.sh vitprio0)
+            "vitprio0": ["-DED_VITSM_PRIO=0"], "vitdepth1": ["-DED_VITSM_DEPTH=1"], "tabbuild256": ["-DED_TAB_BUILD_THREADS=256"],
             # timing experiments on k_emit_tab_sm (wrong results by construction): without its stores / LDS look-ups / global look-ups
             "xnostore": ["-DED_SM_X_NOSTORE"], "xnolds": ["-DED_SM_X_NOLDS"], "xnoglobal": ["-DED_SM_X_NOGLOBAL"],
             "xnoldsglobal": ["-DED_SM_X_NOLDS", "-DED_SM_X_NOGLOBAL"],

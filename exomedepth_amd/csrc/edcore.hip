@@ -112,11 +112,21 @@ __device__ __forceinline__ double cov_expected(const double* __restrict__ X, int
 }
 
 // consts layout: [9][S] = a1_del,a2_del,C_del, a1_norm,a2_norm,C_norm, a1_dup,a2_dup,C_dup ; flags[3][S]
+// Also zeroes, when handed them, the small per-run words the kernels behind it accumulate into -- the error / table counters (64 bytes),
+// the table statistics of k_tab_stats [3][S], the list of samples without tables, the strict lists' counters: as hipMemsetAsync each
+// of them was a fill kernel of its own on the stream that carries the emissions, queued behind whatever the chip was busy with
+// (round 5 trace: 0.6 ms for the first one next to a starting k_viterbi_sm).
 __global__ void k_sample_consts(const double* __restrict__ phi, const double* __restrict__ expected, double mixture,
-                                int64_t S, double* __restrict__ consts, int* __restrict__ cflags)
+                                int64_t S, double* __restrict__ consts, int* __restrict__ cflags, unsigned long long* __restrict__ z_nerr,
+                                unsigned long long* __restrict__ z_tacc, unsigned int* __restrict__ z_notab, unsigned int* __restrict__ z_cold_n,
+                                int n_cold_n)
 {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (z_nerr && s < 8) z_nerr[s] = 0ull;
+  if (z_notab && s == 0) z_notab[0] = 0u;
+  if (z_cold_n) for (int64_t i = s; i < n_cold_n; i += (int64_t)gridDim.x * blockDim.x) z_cold_n[i] = 0u;
   if (s >= S) return;
+  if (z_tacc) { z_tacc[s] = 0ull; z_tacc[S + s] = 0ull; z_tacc[2 * S + s] = 0ull; }
   const double e = expected[s];
   const double sd = __builtin_sqrt((phi[s] * e) * (1. - e));
   double ep[3];
@@ -1779,6 +1789,8 @@ struct ed_batch {
   int64_t Epad = 0;
   std::vector<int64_t> seg_sm;   // segments in blocks of 64 exons (first block, first exon, end exon), job order
   int2* d_blk_sm = nullptr;      // per block of that numbering: (its first exon, the end of its chromosome)
+  unsigned int* d_vit_queue = nullptr;   // [8][2] work counters of k_viterbi_sm's persistent grid (one pair per launch group in flight; self-resetting)
+  int vit_waves = 1024;          // waves of that grid: the SIMDs of the device (tab_setup_sm)
   int64_t nblk_sm = 0;
   bool rows_valid = true;
   int fit_mode = 0;          // ed_batch_fit: 0 = maximum likelihood (Newton); 1 = aod::betabin's procedure (Nelder-Mead from the
@@ -2301,7 +2313,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   if (!b) return;
   fitwork_free(b->fitw);
   binswork_free(b->binsw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_notab, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t, b->d_test_sm, b->d_ref_sm, b->d_loglik_sm, b->d_blk_sm};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_notab, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t, b->d_test_sm, b->d_ref_sm, b->d_loglik_sm, b->d_blk_sm, b->d_vit_queue};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -2479,7 +2491,7 @@ static int tab_setup_sm(ed_batch* b)
   if (b->d_loglik_sm) return ED_OK;
   const ed_plan* p = b->plan;
   const int64_t S = b->S, E = p->E;
-  b->Epad = ((E + 15) / 16) * 16 + 64;    // (k_viterbi_sm loads whole tiles up to three tiles past a chromosome's end)
+  b->Epad = ((E + 15) / 16) * 16 + 96;    // (k_viterbi_sm loads whole tiles up to four tiles past a chromosome's end)
   // Blocks of 64 exons on the ABSOLUTE exon grid, clipped to their chromosome: every block but the first and last of a chromosome
   // starts at a multiple of 64 exons, so that a wave's three 512-byte stores are whole aligned 128-byte lines of the [S][3][Epad]
   // matrix (chromosome-relative blocks made nearly every store begin and end with a partial line).
@@ -2503,11 +2515,18 @@ static int tab_setup_sm(ed_batch* b)
   A((void**)&b->d_test_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
   A((void**)&b->d_ref_sm, (size_t)std::max<int64_t>(E, 1) * S * 4);
   A((void**)&b->d_blk_sm, bm.size() * 8);
+  A((void**)&b->d_vit_queue, 64);
   A((void**)&b->d_loglik_sm, ((size_t)S * 3 * b->Epad + 512) * 8);     // (last: it is the "already set up" sentinel)
+  if (ok && hipMemset(b->d_vit_queue, 0, 64) != hipSuccess) ok = false;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) b->vit_waves = prop.multiProcessorCount * 4;
+    if (const char* e = getenv("ED_VIT_WAVES")) { if (atoi(e) > 0) b->vit_waves = atoi(e); }      // (experiments: profiles/r05_viterbi_waves.txt)
+  }
   if (ok && hipMemset(b->d_loglik_sm, 0, ((size_t)S * 3 * b->Epad + 512) * 8) != hipSuccess) ok = false;
   if (ok && hipMemcpy(b->d_blk_sm, bm.data(), bm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
   if (!ok) {     // all of them or none
-    void** ptrs[] = {(void**)&b->d_test_sm, (void**)&b->d_ref_sm, (void**)&b->d_blk_sm, (void**)&b->d_loglik_sm};
+    void** ptrs[] = {(void**)&b->d_test_sm, (void**)&b->d_ref_sm, (void**)&b->d_blk_sm, (void**)&b->d_vit_queue, (void**)&b->d_loglik_sm};
     for (void** q : ptrs) { if (*q) (void)hipFree(*q); *q = nullptr; }
     (void)hipGetLastError();
     return ed_fail(ED_ERR_NOMEM, "emit mode 2: cannot allocate the sample-major matrices (E=%lld S=%lld)", (long long)E, (long long)S);
@@ -2537,15 +2556,13 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
 {
   if (int rc = tab_setup(b)) return rc;
   const int64_t E = b->plan->E, S = b->S;
-  const int step = E >= 4096 ? 16 : 1;
-  HIP_TRY(hipMemsetAsync(b->d_tacc, 0, (size_t)3 * S * 8, st));
-  HIP_TRY(hipMemsetAsync(b->d_notab, 0, 4, st));
+  const int step = E >= 4096 ? 16 : 1;     // (d_tacc, d_notab[0], d_cold_n were zeroed by k_sample_consts, launched right before this on the same stream)
   if (E > 0 && b->counts_layout == 1)
     hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc);
   else if (E > 0)
     hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
                        step, b->d_tacc);
-  hipLaunchKernelGGL(k_tab_build, dim3((unsigned)S, 3), dim3(kTabBlock), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach, b->tab_capY, b->tab_capR,
+  hipLaunchKernelGGL(k_tab_build, dim3((unsigned)S, 3), dim3(kTabBuildBlock), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach, b->tab_capY, b->tab_capR,
                      b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab);
   HIP_TRY(hipGetLastError());
   return ED_OK;
@@ -2563,7 +2580,11 @@ static int batch_prepare(ed_batch* b, const double* d_phi, const double* d_expec
   if (b->fused) return ED_OK;
   if (b->emit_mode >= 1 && (!d_test || !d_ref)) return ED_OK;   // the tables need the counts: made by the run itself
   const int64_t S = b->S;
-  hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S, b->d_consts, b->d_cflags);
+  if (b->emit_mode >= 1) { if (int rc = tab_setup(b)) return rc; }
+  // (the error / table counters of the batch's previous run may not have been read yet: they are zeroed by the run itself)
+  hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S, b->d_consts, b->d_cflags,
+                     (unsigned long long*)nullptr, b->emit_mode >= 1 ? b->d_tacc : (unsigned long long*)nullptr,
+                     b->emit_mode >= 1 ? b->d_notab : (unsigned int*)nullptr, b->emit_mode >= 1 ? b->d_cold_n : (unsigned int*)nullptr, kColdLists + 1);
   if (b->emit_mode >= 1) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
   else
   hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S, b->d_tab_gl,
@@ -2601,13 +2622,15 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   b->split_recorded = false;
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected; b->last_layout = b->counts_layout;
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
-  HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 64, st));
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
   const bool ready = plain && b->prepared && b->prepared_phi == d_phi && b->prepared_exp == d_expected && b->prepared_mix == mixture && !b->fused;
   b->prepared = false;
+  if (!plain || ready) HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 64, st));     // (otherwise: k_sample_consts below)
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
   if (plain && !ready) {
+    if (tabm) { if (int rc = tab_setup(b)) return rc; }
     hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
-                       b->d_consts, b->d_cflags);
+                       b->d_consts, b->d_cflags, b->d_nerr, tabm ? b->d_tacc : (unsigned long long*)nullptr, tabm ? b->d_notab : (unsigned int*)nullptr,
+                       tabm ? b->d_cold_n : (unsigned int*)nullptr, kColdLists + 1);
     if (tabm) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
     else if (!b->fused)
       hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S,
@@ -2681,7 +2704,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       // previous group's Viterbi workgroups (side stream) are dispatched into the slots freed at that launch
       // boundary instead of queueing behind this group's thousands of pending workgroups.
       const int64_t blk0 = segv[3 * j0], nblk = plain ? segv[3 * j1] - blk0 : 0;
-      if (tabm) HIP_TRY(hipMemsetAsync(b->d_cold_n, 0, (size_t)(kColdLists + 1) * 4, st));
+      if (tabm && g > 0) HIP_TRY(hipMemsetAsync(b->d_cold_n, 0, (size_t)(kColdLists + 1) * 4, st));   // (group 0: zeroed by k_sample_consts)
       const int64_t head = tabsm ? ((g > 0 && nblk > 512) ? 128 : 0) : ((g > 0 && nblk > 2 * kEmitHeadBlocks) ? kEmitHeadBlocks : 0);
       if (!plain && g == 0)   // one launch over every cell; the Viterbi groups follow it
       {
@@ -2760,10 +2783,14 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         HIP_TRY(hipStreamWaitEvent(side, b->zero_ev, 0));
       }
       const dim3 gw((unsigned)((S + 63) / 64), (unsigned)((p->max_words + 3) / 4), (unsigned)(j1 - j0));
-      if (tabsm)
-        hipLaunchKernelGGL(k_viterbi_sm, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
+      if (tabsm) {
+        // a persistent grid, one wave per SIMD, pulling (chromosome, sample group) items longest chromosome first (edtab.inc)
+        const unsigned n_groups = (unsigned)((S + kVitChains - 1) / kVitChains), n_items = n_groups * (unsigned)(j1 - j0);
+        const unsigned n_waves = std::min<unsigned>(n_items, (unsigned)std::max(1, b->vit_waves));
+        hipLaunchKernelGGL(k_viterbi_sm, dim3(n_waves), dim3(kWave), 0,
                            side, b->d_loglik_sm, b->Epad, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
-                           b->d_last, b->d_job_off, b->d_job_chrom, j0);
+                           b->d_last, b->d_job_off, b->d_job_chrom, j0, b->d_vit_queue + 2 * (g % 8), n_groups, n_items);
+      }
       else
       hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((S + kVitChains - 1) / kVitChains), (unsigned)(j1 - j0)), dim3(kWave), 0,
                          side, b->d_loglik, p->d_lt3, p->c0, p->c1, p->d_chrom_off, p->d_tile_off, S, C, b->d_bp,
@@ -3300,11 +3327,9 @@ ED_EXPORT int ed_batch_table_stats(ed_batch* b, int64_t out[4])
   if (!out) return ed_fail(ED_ERR_INVALID, "NULL output");
   out[0] = out[1] = out[2] = out[3] = 0;
   if (!b->d_cold_n || b->emit_mode < 1) return ED_OK;
-  unsigned long long v[3] = {0, 0, 0};
-  unsigned int nnt = 0;
-  if (int rc = ed_d2h(v, b->d_nerr + 2, 24, b->stream)) return rc;
-  if (int rc = ed_d2h(&nnt, b->d_notab, 4, b->stream)) return rc;
-  out[0] = (int64_t)v[0]; out[1] = (int64_t)nnt; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
+  unsigned long long v[4] = {0, 0, 0, 0};
+  if (int rc = ed_d2h(v, b->d_nerr + 2, 32, b->stream)) return rc;
+  out[0] = (int64_t)v[0]; out[1] = (int64_t)v[3]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
   return ED_OK;
 }
 
