@@ -68,6 +68,9 @@ def build(force=False, verbose=False):
 VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             # k_viterbi_sm without its raised wave priority (round 5 A/B: tools/ab.sh vitprio0)
             "vitprio0": ["-DED_VITSM_PRIO=0"], "vitdepth1": ["-DED_VITSM_DEPTH=1"], "tabbuild256": ["-DED_TAB_BUILD_THREADS=256"],
+            # timing experiment (wrong results by construction): k_emit_tab_sm reading its counts as 16-bit elements -- what a 16-bit device-resident
+            # count format would be worth to that kernel (profiles/r05_u16_experiment.txt)
+            "xu16": ["-DED_SM_X_U16"],
             # timing experiments on k_emit_tab_sm (wrong results by construction): without its stores / LDS look-ups / global look-ups
             "xnostore": ["-DED_SM_X_NOSTORE"], "xnolds": ["-DED_SM_X_NOLDS"], "xnoglobal": ["-DED_SM_X_NOGLOBAL"],
             "xnoldsglobal": ["-DED_SM_X_NOLDS", "-DED_SM_X_NOGLOBAL"],
