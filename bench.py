@@ -402,6 +402,9 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
                                                   "times and counts are rank 0's" % (S, S * world))}
 
 
+PIPELINED_SLABS_IN_FLIGHT = 6      # configs[1] leg: a slab's latency (~2.5 ms, its longest chromosome's chain) over its issue interval
+
+
 def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps, opts={}):
     """BASELINE configs[1]: 200 000 exons x 64 samples, phi given (no fit) -- the first 64 columns of the batch through the cohort
     pipeline (three slabs in flight: 0.91 ms per slab against 1.07 with two and 1.08-1.2 with four to eight -- at 64 samples a slab is
@@ -413,19 +416,21 @@ def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps, opts={}):
         t64, r64 = t64.t().contiguous(), r64.t().contiguous()
     ph, pe = phi[:n].contiguous(), p[:n].contiguous()
     res = {}
-    for name, in_flight in (("pipelined", 3), ("one_at_a_time", 1)):
+    for name, in_flight in (("pipelined", PIPELINED_SLABS_IN_FLIGHT), ("one_at_a_time", 1)):
         co = ed.Cohort(plan, n, in_flight, **opts)
-        for _ in range(3):
+        for _ in range(in_flight + 2):
             co.submit(t64, r64, phi=ph, expected=pe, n_samples=n)
         co.drain()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             tk = co.submit(t64, r64, phi=ph, expected=pe, n_samples=n)
+        t_issued = time.perf_counter() - t0
         co.drain()
         el = time.perf_counter() - t0
         b, _, _ = co.batch(tk)
-        res[name] = {"ms_per_step": el / steps * 1e3, "value": E * n * steps / el, "n_calls": b.n_calls()}
+        res[name] = {"ms_per_step": el / steps * 1e3, "value": E * n * steps / el, "n_calls": b.n_calls(), "slabs_in_flight": in_flight,
+                     "host_ms_per_submit": t_issued / steps * 1e3}
         co.close()
     return {"workload": "BASELINE.json configs[1]: %d exons x 64 samples, phi given per sample (no fit), 1 GPU" % E, "steps": steps,
             "unit": "exons*samples/s", **res}

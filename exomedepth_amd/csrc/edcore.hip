@@ -119,8 +119,10 @@ __device__ __forceinline__ double cov_expected(const double* __restrict__ X, int
 __global__ void k_sample_consts(const double* __restrict__ phi, const double* __restrict__ expected, double mixture,
                                 int64_t S, double* __restrict__ consts, int* __restrict__ cflags, unsigned long long* __restrict__ z_nerr,
                                 unsigned long long* __restrict__ z_tacc, unsigned int* __restrict__ z_notab, unsigned int* __restrict__ z_cold_n,
-                                int n_cold_n)
+                                int n_cold_n, double* __restrict__ phi_copy, double* __restrict__ exp_copy)
 {
+  // phi_copy / exp_copy (cohort pipeline, parameters given by the caller): the slot's own copy of the slab's (phi, expected) -- what
+  // the accessors and the call decoration read later -- written here instead of by two device-to-device copies on the emission stream
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (z_nerr && s < 8) z_nerr[s] = 0ull;
   if (z_notab && s == 0) z_notab[0] = 0u;
@@ -128,6 +130,7 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
   if (s >= S) return;
   if (z_tacc) { z_tacc[s] = 0ull; z_tacc[S + s] = 0ull; z_tacc[2 * S + s] = 0ull; }
   const double e = expected[s];
+  if (phi_copy) { phi_copy[s] = phi[s]; exp_copy[s] = e; }
   const double sd = __builtin_sqrt((phi[s] * e) * (1. - e));
   double ep[3];
   state_props(e, mixture, ep);
@@ -1740,6 +1743,9 @@ struct ed_batch {
   // Emission launch cut in two (single-group mode only): the first `split_frac` of the workgroups, an event, the rest.  The
   // cohort pipeline (edcohort.inc) makes the NEXT slab's dispersion fit wait for that event, so that the fit is issued --
   // in stream order, whatever the host's timing -- while this slab's emissions are under way.
+  const double* src_phi = nullptr;      // cohort pipeline, given parameters: k_sample_consts of the next run / prepare reads (phi, expected) from
+  const double* src_exp = nullptr;      // here and writes the copies the run is handed (the slot's arrays); cleared when consumed
+  bool prepared_zeroed = false;         // ... batch_prepare also zeroed the run's counters (the cohort says when that is safe)
   bool prepared = false;                // the per-sample constants and tables of the NEXT run are already made (batch_prepare)
   const double* prepared_phi = nullptr; // ... from these parameters
   const double* prepared_exp = nullptr;
@@ -2575,16 +2581,21 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
 // tables) and the next ed_batch_run after this work (an event); ed_batch_run then skips the two kernels if it is handed the
 // same parameters.
 static int batch_prepare(ed_batch* b, const double* d_phi, const double* d_expected, double mixture, hipStream_t st,
-                         const int32_t* d_test = nullptr, const int32_t* d_ref = nullptr)
+                         const int32_t* d_test = nullptr, const int32_t* d_ref = nullptr, bool zero_counters = false)
 {
   if (b->fused) return ED_OK;
   if (b->emit_mode >= 1 && (!d_test || !d_ref)) return ED_OK;   // the tables need the counts: made by the run itself
   const int64_t S = b->S;
   if (b->emit_mode >= 1) { if (int rc = tab_setup(b)) return rc; }
   // (the error / table counters of the batch's previous run may not have been read yet: they are zeroed by the run itself)
-  hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S, b->d_consts, b->d_cflags,
-                     (unsigned long long*)nullptr, b->emit_mode >= 1 ? b->d_tacc : (unsigned long long*)nullptr,
-                     b->emit_mode >= 1 ? b->d_notab : (unsigned int*)nullptr, b->emit_mode >= 1 ? b->d_cold_n : (unsigned int*)nullptr, kColdLists + 1);
+  const bool from_src = b->src_phi && b->src_exp;
+  hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, from_src ? b->src_phi : d_phi, from_src ? b->src_exp : d_expected, mixture, S,
+                     b->d_consts, b->d_cflags,
+                     zero_counters ? b->d_nerr : (unsigned long long*)nullptr, b->emit_mode >= 1 ? b->d_tacc : (unsigned long long*)nullptr,
+                     b->emit_mode >= 1 ? b->d_notab : (unsigned int*)nullptr, b->emit_mode >= 1 ? b->d_cold_n : (unsigned int*)nullptr, kColdLists + 1,
+                     from_src ? const_cast<double*>(d_phi) : (double*)nullptr, from_src ? const_cast<double*>(d_expected) : (double*)nullptr);
+  b->src_phi = b->src_exp = nullptr;
+  b->prepared_zeroed = zero_counters;
   if (b->emit_mode >= 1) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
   else
   hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S, b->d_tab_gl,
@@ -2621,16 +2632,20 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   b->stream = tail;
   b->split_recorded = false;
   b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected; b->last_layout = b->counts_layout;
+  struct SrcClear { ed_batch* b; ~SrcClear() { b->src_phi = b->src_exp = nullptr; } } src_clear{b};   // (whatever path the run takes)
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
   const bool ready = plain && b->prepared && b->prepared_phi == d_phi && b->prepared_exp == d_expected && b->prepared_mix == mixture && !b->fused;
   b->prepared = false;
-  if (!plain || ready) HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 64, st));     // (otherwise: k_sample_consts below)
+  if (!plain || (ready && !b->prepared_zeroed)) HIP_TRY(hipMemsetAsync(b->d_nerr, 0, 64, st));     // (otherwise: k_sample_consts, below or in batch_prepare)
+  b->prepared_zeroed = false;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
   if (plain && !ready) {
     if (tabm) { if (int rc = tab_setup(b)) return rc; }
-    hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, d_phi, d_expected, mixture, S,
+    const bool from_src = b->src_phi && b->src_exp;
+    hipLaunchKernelGGL(k_sample_consts, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, from_src ? b->src_phi : d_phi, from_src ? b->src_exp : d_expected, mixture, S,
                        b->d_consts, b->d_cflags, b->d_nerr, tabm ? b->d_tacc : (unsigned long long*)nullptr, tabm ? b->d_notab : (unsigned int*)nullptr,
-                       tabm ? b->d_cold_n : (unsigned int*)nullptr, kColdLists + 1);
+                       tabm ? b->d_cold_n : (unsigned int*)nullptr, kColdLists + 1,
+                       from_src ? const_cast<double*>(d_phi) : (double*)nullptr, from_src ? const_cast<double*>(d_expected) : (double*)nullptr);
     if (tabm) { if (int rc = tab_build(b, d_test, d_ref, st)) return rc; }
     else if (!b->fused)
       hipLaunchKernelGGL(k_emit_tables, dim3((unsigned)((S + 63) / 64), (unsigned)(kEmitTab / 4), 3), dim3(256), 0, st, b->d_consts, S,
