@@ -63,10 +63,16 @@ def test_horner_constants_are_written_by_salu_inside_the_asm():
         _build.build()
     lines = [l.split("//")[0].strip() for l in hz.disassemble(hz.extract_code_object(_build.LIB)).split("\n")]
     lines = [l for l in lines if l]
-    n = 0
+    n = n_other = 0
     for i, l in enumerate(lines):
         if l.startswith("v_fma_f64") and l.endswith("s[28:29]"):
-            n += 1
-            assert lines[i - 1].startswith("s_mov_b32 s29, 0x") or lines[i - 1].startswith("s_mov_b32 s29, "), lines[i - 3:i + 1]
-            assert lines[i - 2].startswith("s_mov_b32 s28, "), lines[i - 3:i + 1]
-    assert n > 5000
+            if lines[i - 1].startswith("s_mov_b32 s29, ") and lines[i - 2].startswith("s_mov_b32 s28, "):
+                n += 1              # the asm's triple
+                continue
+            # the register allocator may hand s[28:29] to a scalar double of its own (k_tab_build's logarithm keeps a coefficient there):
+            # compiler-generated, hazard-padded by LLVM and covered by the scan above -- but no VALU may have written the pair just before
+            n_other += 1
+            for back in (1, 2):
+                w = lines[i - back]
+                assert not (w.startswith("v_") and any(r in w.split(",")[0] for r in ("s28", "s29", "s[28:29]"))), lines[i - 3:i + 1]
+    assert n > 5000 and n_other < n // 20, (n, n_other)
