@@ -66,6 +66,8 @@ def build(force=False, verbose=False):
 
 # Diagnostic variants of the library (same sources, different code generation); never loaded by the package itself.
 VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
+            # the library with its experiment knobs (environment variables ED_TAB_REACH, ED_TAB_TW, ED_VIT_WAVES, ED_SM_NSPLIT, ED_COHORT_*) enabled
+            "knobs": ["-DED_EXPERIMENT_KNOBS"],
             # k_viterbi_sm without its raised wave priority (round 5 A/B: tools/ab.sh vitprio0)
             "vitprio0": ["-DED_VITSM_PRIO=0"], "vitdepth1": ["-DED_VITSM_DEPTH=1"], "tabbuild256": ["-DED_TAB_BUILD_THREADS=256"],
             # timing experiment (wrong results by construction): k_emit_tab_sm reading its counts as 16-bit elements -- what a 16-bit device-resident

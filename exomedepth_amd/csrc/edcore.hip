@@ -47,6 +47,19 @@
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
+// Experiment knobs (table reach / tile width, waves of the persistent Viterbi grid, shares per sample of the emission launch, the cohort
+// pipeline's queue layout) are read from the environment only in builds made with -DED_EXPERIMENT_KNOBS (exomedepth_amd/_build.py variant
+// "knobs"): the shipped library's behaviour does not depend on the caller's environment.
+static const char* ed_knob(const char* name)
+{
+#ifdef ED_EXPERIMENT_KNOBS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 static int ed_fail(int code, const char* fmt, ...)
 {
   char buf[512];
@@ -2527,7 +2540,7 @@ static int tab_setup_sm(ed_batch* b)
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) b->vit_waves = prop.multiProcessorCount * 4;
-    if (const char* e = getenv("ED_VIT_WAVES")) { if (atoi(e) > 0) b->vit_waves = atoi(e); }      // (experiments: profiles/r05_viterbi_waves.txt)
+    if (const char* e = ed_knob("ED_VIT_WAVES")) { if (atoi(e) > 0) b->vit_waves = atoi(e); }      // (experiments: profiles/r05_viterbi_waves.txt)
   }
   if (ok && hipMemset(b->d_loglik_sm, 0, ((size_t)S * 3 * b->Epad + 512) * 8) != hipSuccess) ok = false;
   if (ok && hipMemcpy(b->d_blk_sm, bm.data(), bm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
@@ -2669,6 +2682,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
     }
     if (tabsm) {    // n, base: blocks of 64 exons; every sample gets nsplit workgroups that share them
       int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(16, (512 + S - 1) / S));
+      if (const char* e = ed_knob("ED_SM_NSPLIT")) { if (atoi(e) > 0) nsplit = atoi(e); }
       nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(nsplit, n / 32));
       const int64_t nwg = ((S + 7) / 8) * 8 * nsplit;
       hipLaunchKernelGGL(k_emit_tab_sm, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
@@ -3094,8 +3108,8 @@ ED_EXPORT int ed_batch_set_emit_mode(ed_batch* b, int mode)
   if (mode != 0 && mode != 1 && mode != 2) return ed_fail(ED_ERR_INVALID, "ed_batch_set_emit_mode: 0 (strict), 1 (tables, exon-major tiles) or 2 (tables, sample-major)");
   if (mode >= 1) {
     HIP_TRY(hipSetDevice(b->plan->device));
-    if (const char* e = getenv("ED_TAB_REACH")) { if (!b->d_tabs && atof(e) >= 1.0) b->tab_reach = atof(e); }   // (experiments)
-    if (const char* e = getenv("ED_TAB_TW")) { const int tw = atoi(e); if (!b->d_tabs && (tw == 4 || tw == 8 || tw == 16 || tw == 32 || tw == 64)) b->tab_tw = tw; }
+    if (const char* e = ed_knob("ED_TAB_REACH")) { if (!b->d_tabs && atof(e) >= 1.0) b->tab_reach = atof(e); }   // (experiments)
+    if (const char* e = ed_knob("ED_TAB_TW")) { const int tw = atoi(e); if (!b->d_tabs && (tw == 4 || tw == 8 || tw == 16 || tw == 32 || tw == 64)) b->tab_tw = tw; }
     if (int rc = tab_setup(b)) return rc;
     if (mode == 2) { if (int rc = tab_setup_sm(b)) return rc; }
   }
