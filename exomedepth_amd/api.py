@@ -637,7 +637,8 @@ class Cohort:
 
     def submit_host_test(self, test, ref, layout, phi=None, expected=None, mixture=1.0, n_samples=None, row_stride=None):
         """one slab whose TEST counts come from host memory (as submit_host) and whose references are on the device already
-        (ref: (n_exons, n) int32 CUDA tensor / DeviceArray -- e.g. a window of cohort_select_reference_sets' aggregate references)"""
+        (ref: int32 CUDA tensor / DeviceArray in the cohort's DEVICE layout -- (n_exons, n) with counts_layout 0, e.g. a window of
+        cohort_select_reference_sets' aggregate references; (n, n_exons) with counts_layout 1)"""
         test = _host_slab(test, layout)
         if test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
             raise ValueError("test must be int32 or uint16")

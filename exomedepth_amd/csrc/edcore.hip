@@ -2557,6 +2557,7 @@ static int tab_setup_sm(ed_batch* b)
 static int ensure_loglik_rows(ed_batch* b)
 {
   if (b->rows_valid) return ED_OK;
+  HIP_TRY(hipSetDevice(b->plan->device));      // (an accessor may be called from a thread whose current device is another one)
   const int64_t E = b->plan->E, S = b->S;
   if (!b->d_loglik) {
     if (hipMalloc((void**)&b->d_loglik, (size_t)std::max<int64_t>(E, 1) * 3 * S * 8) != hipSuccess)

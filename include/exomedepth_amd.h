@@ -244,7 +244,10 @@ int ed_batch_wait(ed_batch* batch, void* stream);
 int ed_batch_set_viterbi_overlap(ed_batch* batch, int on);
 
 /* device-resident results of the last ed_batch_run */
-const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples] */
+const double* ed_batch_loglik(const ed_batch* batch);  /* [n_exons][3][n_samples]; emit mode 2 keeps the matrix as [n_samples][3][n_exons + pad]:
+                                                         * the first call after a run then ENQUEUES the conversion on the run's stream (and allocates
+                                                         * the [n_exons][3][n_samples] form once) -- not for two threads at a time; NULL + ed_last_error()
+                                                         * on failure */
 const uint8_t* ed_batch_path(const ed_batch* batch);   /* [n_exons][n_samples]    */
 const ed_call* ed_batch_calls(const ed_batch* batch);  /* device array, length ed_batch_n_calls(); call that first: it
                                                          * also re-sizes the table if the run produced more calls than
@@ -499,8 +502,10 @@ void* ed_cohort_stream(ed_cohort* cohort);               /* the pipeline's main 
 int ed_cohort_stage_ms_total(ed_cohort* cohort, double ms_total[5], int64_t* n_runs, int64_t* n_fits);
 int ed_cohort_n_emit_launches(ed_cohort* cohort);
 
-/* ed_cohort_submit_host with only the TEST counts in host memory and the references on the device (d_ref: int32
- * [n_exons][n_samples] sample-minor, complete when this is called).  In the reference's workflow a sample's reference is the sum of
+/* ed_cohort_submit_host with only the TEST counts in host memory and the references on the device (d_ref: int32, complete when this
+ * is called, in the COHORT's device layout: [n_exons][n_samples] with option counts_layout = 0 -- what ed_cohort_select_reference_sets
+ * writes -- and [n_samples][n_exons] with counts_layout = 1; the host matrix's own layout is the `layout` argument, as for
+ * ed_cohort_submit_host).  In the reference's workflow a sample's reference is the sum of
  * other samples of the same cohort (vignette/vignette.Rnw:390-402): ed_cohort_select_reference_sets makes it on the device from counts
  * uploaded once, so only one matrix per slab crosses the link. */
 int ed_cohort_submit_host_test(ed_cohort* cohort, const void* test, const int32_t* d_ref, int64_t n_samples, int layout, int wire,
