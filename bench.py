@@ -362,8 +362,10 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
     stream = torch.cuda.current_stream()
     times = {"upload_ms": [], "reference_sets_ms": [], "calls_ms": [], "total_ms": []}
     n_calls = n_chosen = None
-    co = ed.Cohort(plan, S, 1, **({"emit_mode": emit_mode} if emit_mode else {}))
-    ref_t = torch.empty((E, S), dtype=torch.int32, device=test.device)
+    sm = emit_mode == 2 and world == 1 and S <= 4096     # sample-major hand-over: aggregate references and the transposed counts straight from the reference-set stage
+    co = ed.Cohort(plan, S, 1, **({"emit_mode": emit_mode, "counts_layout": 1 if sm else 0} if emit_mode else {}))
+    ref_t = torch.empty((S, E) if sm else (E, S), dtype=torch.int32, device=test.device)
+    counts_sm = torch.empty((S, E), dtype=torch.int32, device=test.device) if sm else None
     for rep in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -376,10 +378,10 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
             rs = eddist.cohort_reference_sets_sharded(dcounts, S * world, bl, 10000, max_refs=32)
             ref_t = torch.as_tensor(eddist._DevicePointer(rs["reference"].ptr.value, (E, S), "<i4"), device=test.device)
         else:
-            rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32, reference_out=ref_t)
+            rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32, reference_out=ref_t, sample_major=sm, counts_sm_out=counts_sm)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        tk = co.submit(dcounts, ref_t, n_samples=S)     # (two half-cohort slabs through the pipeline were tried: 17 ms against 12.7 -- the slicing copies cost more than the overlap gives)
+        tk = co.submit(counts_sm if sm else dcounts, ref_t, n_samples=S)     # (two half-cohort slabs through the pipeline were tried: 17 ms against 12.7 -- the slicing copies cost more than the overlap gives)
         co.wait(tk)
         b, _, _ = co.batch(tk)
         n_calls = b.n_calls()
@@ -394,7 +396,8 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
     co.close(); pin.free()
     med = {k: float(np.median(v)) for k, v in times.items()}
     return {"workload": "one cohort of %d samples x %d exons: counts from pinned host memory (uint16) -> reference sets of every sample against all "
-                        "others (n.bins.reduced 10000, <= 32 candidates) + aggregate references on the device -> fit + emissions + Viterbi + calls; "
+                        "others (n.bins.reduced 10000, <= 32 candidates) + aggregate references on the device (sample-major, with the transposed counts, "
+                        "when the calls run in the sample-major table mode on one rank) -> fit + emissions + Viterbi + calls; "
                         "stages one after the other (one cohort, nothing to overlap with), median of %d" % (S, E, reps),
             **med, "value": E * S * world / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls, "table_stats": tstats,
             "ranks": world, "choice_checksum_rank0": checksum,

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("ed_select_reference_set_part", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     ("ed_cohort_select_reference_sets", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     ("ed_cohort_select_reference_sets_range", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    ("ed_cohort_select_reference_sets_sm", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     ("ed_cohort_select_reference_sets_host", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     ("ed_release_scratch", C.c_int, []),
     ("ed_refset_finalize", C.c_int, [_vp, _i64, C.POINTER(_i32)]),

@@ -1047,14 +1047,17 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
 
 
 def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_refs=32, want_reference=True, want_correlations=False,
-                                 reference_out=None, test_range=None):
+                                 reference_out=None, test_range=None, sample_major=False, counts_sm_out=None):
     """select.reference.set for every sample of a cohort against all the others (reference vignette/vignette.Rnw:390-402 loop;
     R/optimize_reference_set.R:53-148 per sample), in one call.
 
     counts: (E, S) int32 host array or torch CUDA tensor.  Returns dict(n_chosen (S,), choice (S, K) -1 padded,
     summary.stats (S, K) REFSET_DTYPE, n.bins[, reference: DeviceArray (E, S) aggregate reference][, correlations (S, S)]).
     test_range = (t0, t1): only the samples t0 <= t < t1 as tests (all S still candidates) -- one rank's share of a sample-sharded
-    cohort; the per-test outputs then have t1 - t0 rows / columns (ed_cohort_select_reference_sets_range)."""
+    cohort; the per-test outputs then have t1 - t0 rows / columns (ed_cohort_select_reference_sets_range).
+    sample_major=True: the aggregate references come back sample-major, (n_tests, E) -- R's column-major matrix, what Cohort(emit_mode=2,
+    counts_layout=1) takes -- and counts_sm_out (an (S, E) int32 device array), when given, receives the count matrix transposed alongside
+    (ed_cohort_select_reference_sets_sm)."""
     keep = []
     E, S = int(counts.shape[0]), int(counts.shape[1])
     t0, t1 = (0, S) if test_range is None else (int(test_range[0]), int(test_range[1]))
@@ -1070,14 +1073,22 @@ def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_
     corr = np.zeros((Sr, S)) if want_correlations else None
     ref = DeviceArray(nbytes=E * Sr * 4) if (want_reference and reference_out is None) else None
     if ref is not None:
-        ref.host_dtype, ref.shape = np.dtype(np.int32), (E, Sr)
+        ref.host_dtype, ref.shape = np.dtype(np.int32), ((Sr, E) if sample_major else (E, Sr))
     ref_ptr = ref.ptr if ref is not None else None
     if reference_out is not None:          # the caller's own (E, S) int32 device array (a torch CUDA tensor, say) receives the aggregate references
         ref_ptr = _device_pointer(reference_out, np.int32, keep)
     nsel = C.c_int64(0)
-    check(lib().ed_cohort_select_reference_sets_range(pc, E, S, _ptr(bl) if bl is not None else None, int(n_bins_reduced), K, t0, t1,
-                                                      _ptr(n_chosen), _ptr(choice), _ptr(rows), _ptr(corr) if corr is not None else None,
-                                                      ref_ptr, C.byref(nsel), None))
+    if sample_major:
+        if ref_ptr is None:
+            raise ValueError("sample_major=True returns the aggregate references: want_reference or reference_out")
+        cs_ptr = _device_pointer(counts_sm_out, np.int32, keep) if counts_sm_out is not None else None
+        check(lib().ed_cohort_select_reference_sets_sm(pc, E, S, _ptr(bl) if bl is not None else None, int(n_bins_reduced), K, t0, t1,
+                                                       _ptr(n_chosen), _ptr(choice), _ptr(rows), _ptr(corr) if corr is not None else None,
+                                                       ref_ptr, cs_ptr, C.byref(nsel), None))
+    else:
+        check(lib().ed_cohort_select_reference_sets_range(pc, E, S, _ptr(bl) if bl is not None else None, int(n_bins_reduced), K, t0, t1,
+                                                          _ptr(n_chosen), _ptr(choice), _ptr(rows), _ptr(corr) if corr is not None else None,
+                                                          ref_ptr, C.byref(nsel), None))
     out = {"n_chosen": n_chosen, "choice": choice, "summary.stats": rows, "n.bins": int(nsel.value)}
     if ref is not None:
         out["reference"] = ref

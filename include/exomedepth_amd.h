@@ -419,6 +419,17 @@ int ed_cohort_select_reference_sets_range(const int32_t* d_counts, int64_t n_bin
                                           int32_t* choice, ed_refset_row* rows, double* correlations, int32_t* d_ref_out,
                                           int64_t* n_selected_bins, void* stream);
 
+/* The same with the aggregate references written SAMPLE-MAJOR -- d_ref_sm_out DEVICE int32 [n_tests][n_bins], the memory image of R's
+ * n_bins x n_tests matrix -- and, optionally, the count matrix transposed alongside, d_counts_sm_out DEVICE int32 [n_samples][n_bins]
+ * (NULL = not wanted): what a cohort with options emit_mode = 2, counts_layout = 1 takes as they are (ed_cohort_submit), so the calls that
+ * follow the reference sets (vignette/vignette.Rnw:403-431) neither transpose anything nor leave the sample-major fit.  (One pass over the
+ * counts while a tile of all candidates and the tests' lists fit LDS -- 1024 samples x 32 candidates with room to spare; other geometries through
+ * the [n_bins][n_tests] form and a transposition.) */
+int ed_cohort_select_reference_sets_sm(const int32_t* d_counts, int64_t n_bins, int64_t n_samples, const double* bin_length,
+                                       int64_t n_bins_reduced, int32_t max_refs, int64_t test_begin, int64_t test_end, int32_t* n_chosen,
+                                       int32_t* choice, ed_refset_row* rows, double* correlations, int32_t* d_ref_sm_out,
+                                       int32_t* d_counts_sm_out, int64_t* n_selected_bins, void* stream);
+
 /* ed_cohort_select_reference_sets keeps its device scratch (about 1.5 GB at 10 000 selected bins x 1024 samples) between calls;
  * this returns it to the device. */
 int ed_release_scratch(void);

@@ -149,3 +149,25 @@ def test_test_ranges_are_the_rows_of_the_whole_cohort_call(edlib):
         assert np.array_equal(part["reference"].to_host(), ref_whole[:, t0:t1])
     with pytest.raises(Exception, match="tests"):
         edlib.cohort_select_reference_sets(counts, bl, 2000, test_range=(5, 5))
+
+
+@pytest.mark.parametrize("S,E", [(64, 20000), (150, 4001), (1100, 3000), (2100, 700)])
+def test_sample_major_outputs_are_the_transposes(edlib, S, E):
+    """ed_cohort_select_reference_sets_sm: the aggregate references sample-major (and the count matrix transposed alongside) are, bit for
+    bit, the transposes of what ed_cohort_select_reference_sets writes -- tiles of 32 / 16 / 8 rows, ragged last tile, a share of the
+    tests -- and feed a cohort with counts_layout = 1 to the same calls"""
+    counts, bl = _cohort(E=E, S=S, seed=11 + S)
+    a = edlib.cohort_select_reference_sets(counts, bl, 2000, max_refs=32)
+    want = a["reference"].to_host().reshape(E, S)
+    cs = edlib.DeviceArray(nbytes=E * S * 4)
+    cs.host_dtype, cs.shape = np.dtype(np.int32), (S, E)
+    b = edlib.cohort_select_reference_sets(counts, bl, 2000, max_refs=32, sample_major=True, counts_sm_out=cs)
+    assert np.array_equal(a["choice"], b["choice"]) and np.array_equal(a["n_chosen"], b["n_chosen"])
+    assert np.array_equal(b["reference"].to_host().reshape(S, E), want.T)
+    assert np.array_equal(cs.to_host().reshape(S, E), counts.T)
+    t0, t1 = S // 3, S // 3 + max(1, S // 4)
+    c = edlib.cohort_select_reference_sets(counts, bl, 2000, max_refs=32, sample_major=True, test_range=(t0, t1))
+    assert np.array_equal(c["reference"].to_host().reshape(t1 - t0, E), want.T[t0:t1])
+    # a candidate list longer than the one-pass kernel holds: the same result through the [n_bins][n_tests] form
+    d = edlib.cohort_select_reference_sets(counts, bl, 2000, max_refs=min(S - 1, 140), sample_major=True, counts_sm_out=cs)
+    assert np.array_equal(d["reference"].to_host().reshape(S, E), want.T) and np.array_equal(cs.to_host().reshape(S, E), counts.T)
