@@ -28,6 +28,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <thread>
@@ -1440,12 +1441,20 @@ __global__ void k_fit_skip_prefixes(const double* __restrict__ eta, int* __restr
   skip_from[j] = from;
 }
 
+#ifndef ED_FIT_PRE
+#define ED_FIT_PRE 8      // cells of a column requested ahead of the one being consumed (round 5: 4 -> 8)
+#endif
 __global__ void __launch_bounds__(kWave * kFitSub)
 k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const int32_t* __restrict__ ref, int64_t rrs,
             int64_t E, int64_t S, int stride, const double* __restrict__ eta, const double* __restrict__ lam, const int* __restrict__ done,
-            double* __restrict__ partial, int64_t tmod)
+            double* __restrict__ partial, int64_t tmod, const int32_t* __restrict__ colmap = nullptr, const int* __restrict__ n_map = nullptr)
 {
-  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  // colmap (late passes, k_fit_compact): slot j of the launch works on column colmap[j], j < *n_map -- the columns still iterating, packed.
+  // A wave is as slow as its slowest lane: after the third full pass of the cohort reference sets' fit 10 % of the columns were still
+  // iterating and 96 % of the waves with them; packed, the fourth pass costs a tenth.
+  const int64_t j = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (colmap && j >= *n_map) return;
+  const int64_t s = colmap ? (int64_t)colmap[j] : j;
   const int64_t ts = (tmod ? s % tmod : s) * tcs;
   const int sub = threadIdx.y;
   const int64_t chunk = (int64_t)blockIdx.y * kFitSub + sub;
@@ -1461,7 +1470,7 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
   // (trs, tcs) = (S, 1): one test column per sample; (1, 0): one shared test column.
   // The counts of the next kPre cells are requested before the current ones are consumed: ~150 VALU
   // instructions per cell do not cover an HBM round trip on their own.
-  constexpr int kPre = 4;
+  constexpr int kPre = ED_FIT_PRE;
   int yb[kPre], rb[kPre];
 #pragma unroll
   for (int k = 0; k < kPre; ++k) {
@@ -1488,8 +1497,22 @@ k_fit_accum(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const in
       }
     }
   }
-  double* o = partial + (chunk * kFitQ) * S + s;
+  double* o = partial + (chunk * kFitQ) * S + j;       // (the partials of a packed pass sit at the slot, not at the column)
   o[0] = acc.ga; o[S] = acc.gb; o[2 * S] = acc.haa; o[3 * S] = acc.hab; o[4 * S] = acc.hbb; o[5 * S] = cnt;
+}
+
+// the columns still iterating, packed (order irrelevant): colmap[0 .. *n_map)
+__global__ void k_fit_compact(const int* __restrict__ done, int64_t S, int32_t* __restrict__ colmap, int* __restrict__ n_map)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = s < S && !done[s];
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(act);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(n_map, __popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (act) colmap[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
 }
 
 // One Newton step on (eta, lambda) = (logit p, log(a+b)) from the summed gradient/Hessian of the log-likelihood
@@ -1584,14 +1607,17 @@ __device__ __forceinline__ void fit_newton_step(const double (&tot)[kFitQ], doub
 
 __global__ void __launch_bounds__(kWave * kRedY)
 k_fit_update(const double* __restrict__ partial, int64_t nchunk, int64_t S, double* __restrict__ eta,
-             double* __restrict__ lam, int* __restrict__ done, double tol, int final_pass)
+             double* __restrict__ lam, int* __restrict__ done, double tol, int final_pass, const int32_t* __restrict__ colmap = nullptr,
+             const int* __restrict__ n_map = nullptr)
 {
   __shared__ double lds[kFitQ][kRedY][kWave];
-  const int64_t s = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  const bool live = (s < S) && !done[s < S ? s : 0];
+  const int64_t j = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const bool in_map = !colmap || j < *n_map;
+  const int64_t s = (colmap && in_map) ? (int64_t)colmap[j] : j;
+  const bool live = in_map && (s < S) && !done[s < S ? s : 0];
   if (!__syncthreads_or(live ? 1 : 0)) return;   // the whole tile has converged
   double tot[kFitQ];
-  reduce_partials(partial, nchunk, S, s, live, tot, lds);
+  reduce_partials(partial, nchunk, S, j, live, tot, lds);
   if (!live || threadIdx.y != 0) return;
   double e = eta[s], l = lam[s];
   int d = 0;
@@ -2870,6 +2896,8 @@ struct FitWork {
   double* eta = nullptr;
   double* lam = nullptr;
   int* done = nullptr;
+  int32_t* colmap = nullptr;   // [S] the columns still iterating after the third full pass, packed (k_fit_compact)
+  int* n_map = nullptr;        // ... their number
   int* fevals = nullptr;       // fit mode 1: objective evaluations of each sample's Nelder-Mead search
   uint32_t* hist = nullptr;    // count histograms (k_fit_hist; layout and size depend on the geometry, sized for the largest)
   int32_t* ov_y = nullptr;     // [lists][cap][S] cells beyond the histogram range, per row group of k_fit_hist
@@ -2912,6 +2940,8 @@ struct FitWork {
     HIP_TRY(hipMalloc((void**)&eta, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&lam, (size_t)S * 8));
     HIP_TRY(hipMalloc((void**)&done, (size_t)S * 4));
+    HIP_TRY(hipMalloc((void**)&colmap, (size_t)S * 4));
+    HIP_TRY(hipMalloc((void**)&n_map, 4));
     HIP_TRY(hipMalloc((void**)&fevals, (size_t)S * 4));
     HIP_TRY(hipMemset(fevals, 0, (size_t)S * 4));
     HIP_TRY(hipMalloc((void**)&depth, 4));
@@ -2921,11 +2951,11 @@ struct FitWork {
   }
   void release()
   {
-    void* ptrs[] = {partial, eta, lam, done, fevals, hist, ov_y, ov_r, ovn, depth};
+    void* ptrs[] = {partial, eta, lam, done, colmap, n_map, fevals, hist, ov_y, ov_r, ovn, depth};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h_depth) (void)hipHostFree(h_depth);
     h_depth = nullptr;
-    partial = eta = lam = nullptr; done = nullptr; fevals = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr; depth = nullptr;
+    partial = eta = lam = nullptr; done = nullptr; colmap = nullptr; n_map = nullptr; fevals = nullptr; hist = nullptr; ov_y = ov_r = ovn = nullptr; depth = nullptr;
   }
 };
 
@@ -2935,6 +2965,15 @@ static void fitwork_free(FitWork* w)
 }
 
 // Fit S columns: column s has test counts test[e*trs + s*tcs] and reference counts ref[e*rrs + s], e < E.
+// Step below which a full pass of the per-cell form declares a column converged.  Newton converges quadratically (fit_newton_step): a
+// step s leaves an error ~C s^2, and the fit is held to 1e-8 -- 2e-5 leaves ~4e-10 C.  Rounds 1-4 asked for 1e-6, which the third full
+// pass met only barely (its step IS ~1e-6 from the stride-16 start): a fourth pass over most of the cohort reference sets' 32 768 columns,
+// 1.5 of the leg's 9 ms, confirmed what was already there.
+constexpr double kFitStepTol = 2e-5;
+#ifndef ED_FIT_COARSE
+#define ED_FIT_COARSE 4
+#endif
+constexpr int kFitCoarsePasses = ED_FIT_COARSE;   // Newton steps on every 16th exon before the full passes (1 / 16 of a full pass each)
 // use_hist: build count histograms once and iterate on them in one launch (needs one test column per sample laid
 // out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
@@ -3003,15 +3042,25 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   if (skip_K > 0 && tmod > 0 && d_skip_from)
     hipLaunchKernelGGL(k_fit_skip_prefixes, dim3((unsigned)((tmod + 255) / 256)), dim3(256), 0, st, w.eta, w.done, skip_K, tmod, 0.04, d_skip_from);
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
-  const int coarse = (E >= 8192) ? 4 : 0;   // a stride-16 subset below ~500 exons is too noisy to help
+  const int coarse = (E >= 8192) ? kFitCoarsePasses : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   const int cstride = 16;                   // (8 / 4 / 2 measured on the cohort reference sets' 10 000-row fit: 9.9 / 11.1 / 12.3 ms against 9.6)
   for (int it = 0; it < coarse; ++it) {
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, cstride, w.eta, w.lam, w.done, w.partial, tmod);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 0);
   }
+  // (round 5: two passes on every 4th exon between the coarse and the full ones were tried -- 9.2 -> 10.0 ms for the cohort reference sets'
+  //  32 768 columns: the full passes needed are the same three, the medium ones came on top)
   for (int it = 0; it < 10; ++it) {   // converged columns skip their work; typically 3 passes do something
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 1, w.eta, w.lam, w.done, w.partial, tmod);
-    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 1);
+    // from the fourth pass on: the columns still iterating packed into the first waves (k_fit_compact), many columns only
+    const bool packed = it >= 3 && S >= 4096 && w.colmap;
+    if (it == 3 && packed) {
+      HIP_TRY(hipMemsetAsync(w.n_map, 0, 4, st));
+      hipLaunchKernelGGL(k_fit_compact, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, w.done, S, w.colmap, w.n_map);
+    }
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 1, w.eta, w.lam, w.done, w.partial, tmod,
+                       packed ? w.colmap : (const int32_t*)nullptr, packed ? w.n_map : (const int*)nullptr);
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, kFitStepTol, 1,
+                       packed ? w.colmap : (const int32_t*)nullptr, packed ? w.n_map : (const int*)nullptr);
   }
   hipLaunchKernelGGL(k_fit_finish, g1, b1, 0, st, w.eta, w.lam, S, d_phi, d_expected);
   HIP_TRY(hipGetLastError());
