@@ -2608,8 +2608,12 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
   else if (E > 0)
     hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
                        step, b->d_tacc);
-  hipLaunchKernelGGL(k_tab_build, dim3((unsigned)S, 3), dim3(kTabBuildBlock), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach, b->tab_capY, b->tab_capR,
-                     b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab);
+  if (S < 256 && ED_TAB_BUILD_THREADS == 64)
+    hipLaunchKernelGGL(k_tab_build<256>, dim3((unsigned)S, 3), dim3(256), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach, b->tab_capY, b->tab_capR,
+                       b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab);
+  else
+    hipLaunchKernelGGL(k_tab_build<ED_TAB_BUILD_THREADS>, dim3((unsigned)S, 3), dim3(ED_TAB_BUILD_THREADS), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach,
+                       b->tab_capY, b->tab_capR, b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab);
   HIP_TRY(hipGetLastError());
   return ED_OK;
 }
