@@ -2604,7 +2604,7 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
   const int64_t E = b->plan->E, S = b->S;
   const int step = E >= 4096 ? 16 : 1;     // (d_tacc, d_notab[0], d_cold_n were zeroed by k_sample_consts, launched right before this on the same stream)
   if (E > 0 && b->counts_layout == 1)
-    hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc);
+    hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S, 4), dim3(64), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc);
   else if (E > 0)
     hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
                        step, b->d_tacc);
