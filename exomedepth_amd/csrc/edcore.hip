@@ -72,6 +72,25 @@ static int ed_fail(int code, const char* fmt, ...)
   return code;
 }
 
+// No C++ exception leaves the library: the callers are C (R's .Call, ctypes).  Every int-returning entry point is a function-try-block
+// closed by ED_CATCH, which turns what was thrown (in practice std::bad_alloc from a host container, std::system_error from a
+// thread that could not be started) into an error code + ed_last_error().
+static int ed_caught(const char* where) noexcept
+{
+  try { throw; }
+  catch (const std::bad_alloc&) { try { return ed_fail(ED_ERR_NOMEM, "%s: out of host memory", where); } catch (...) { return ED_ERR_NOMEM; } }
+  catch (const std::exception& e) { try { return ed_fail(ED_ERR_STATE, "%s: %s", where, e.what()); } catch (...) { return ED_ERR_STATE; } }
+  catch (...) { try { return ed_fail(ED_ERR_STATE, "%s: unknown C++ exception", where); } catch (...) { return ED_ERR_STATE; } }
+}
+#define ED_CATCH(name) catch (...) { return ed_caught(name); }
+// host threads that are joined on every way out of their scope (an exception between start and join would otherwise terminate the process)
+struct ed_thread_pool {
+  std::vector<std::thread> t;
+  template <class... A> void start(A&&... a) { t.emplace_back(std::forward<A>(a)...); }
+  void join() { for (auto& x : t) if (x.joinable()) x.join(); }
+  ~ed_thread_pool() { join(); }
+};
+
 #define HIP_TRY(expr)                                                                                         \
   do {                                                                                                        \
     hipError_t _e = (expr);                                                                                   \
@@ -1872,14 +1891,15 @@ ED_EXPORT const char* ed_version(void) { return "exomedepth_amd 0.1 (gfx950)"; }
 ED_EXPORT const char* ed_last_error(void) { return g_last_error.c_str(); }
 
 ED_EXPORT int ed_device_count(void)
-{
+try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+ED_CATCH("ed_device_count")
 
 ED_EXPORT int ed_device_info(int device, char* name, size_t name_len, int* compute_units, size_t* total_mem)
-{
+try {
   if (int rc = require_device()) return rc;
   hipDeviceProp_t p;
   HIP_TRY(hipGetDeviceProperties(&p, device));
@@ -1891,34 +1911,40 @@ ED_EXPORT int ed_device_info(int device, char* name, size_t name_len, int* compu
   if (total_mem) *total_mem = p.totalGlobalMem;
   return ED_OK;
 }
+ED_CATCH("ed_device_info")
 
 ED_EXPORT int ed_malloc(void** dptr, size_t bytes)
-{
+try {
   if (!dptr) return ed_fail(ED_ERR_INVALID, "ed_malloc: NULL output pointer");
   if (int rc = require_device()) return rc;
   HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
   return ED_OK;
 }
+ED_CATCH("ed_malloc")
 ED_EXPORT int ed_free(void* dptr)
-{
+try {
   if (dptr) HIP_TRY(hipFree(dptr));
   return ED_OK;
 }
+ED_CATCH("ed_free")
 ED_EXPORT int ed_memcpy_h2d(void* dst, const void* src, size_t bytes)
-{
+try {
   HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return ED_OK;
 }
+ED_CATCH("ed_memcpy_h2d")
 ED_EXPORT int ed_memcpy_d2h(void* dst, const void* src, size_t bytes)
-{
+try {
   HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return ED_OK;
 }
+ED_CATCH("ed_memcpy_d2h")
 ED_EXPORT int ed_synchronize(void* stream)
-{
+try {
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return ED_OK;
 }
+ED_CATCH("ed_synchronize")
 
 // Device-to-host copy ordered on `st` and waited for there.  The accessors use this instead of hipMemcpy, which runs on the
 // legacy null stream and would wait for every blocking stream of the process -- and the streams of the cohort pipeline
@@ -1941,7 +1967,7 @@ struct DevBuf {
 }  // namespace
 
 ED_EXPORT int ed_eval_sf(int which, int64_t n, const double* x, const double* y, double* out)
-{
+try {
   if (n < 0 || !x || !out) return ed_fail(ED_ERR_INVALID, "ed_eval_sf: bad arguments");
   if (int rc = require_device()) return rc;
   if (n == 0) return ED_OK;
@@ -1956,12 +1982,13 @@ ED_EXPORT int ed_eval_sf(int which, int64_t n, const double* x, const double* y,
   HIP_TRY(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
   return ED_OK;
 }
+ED_CATCH("ed_eval_sf")
 
 // ---- drop-in 1: get_loglike_matrix ---------------------------------------------------------
 ED_EXPORT int ed_get_loglike_matrix(const double* phi, const double* expected, const int32_t* total,
                                     const int32_t* observed, int64_t n, double mixture, double* out,
                                     int64_t* n_gsl_errors)
-{
+try {
   if (n < 0 || (n > 0 && (!phi || !expected || !total || !observed || !out)))
     return ed_fail(ED_ERR_INVALID, "ed_get_loglike_matrix: NULL buffer or negative n");
   if (int rc = require_device()) return rc;
@@ -1985,6 +2012,7 @@ ED_EXPORT int ed_get_loglike_matrix(const double* phi, const double* expected, c
   if (n_gsl_errors) *n_gsl_errors = (int64_t)ne;
   return ED_OK;
 }
+ED_CATCH("ed_get_loglike_matrix")
 
 // The text the reference prints while it computes the same matrix: one gsl_error() call = two Rprintf lines
 // (src/error.c:45-48), in the order the reference makes them (rows in order; deletion, normal, duplication;
@@ -1993,7 +2021,7 @@ ED_EXPORT int ed_get_loglike_matrix(const double* phi, const double* expected, c
 ED_EXPORT int ed_get_loglike_matrix_messages(const double* phi, const double* expected, const int32_t* total,
                                              const int32_t* observed, int64_t n, double mixture, char* buf, size_t cap,
                                              size_t* needed)
-{
+try {
   if (n < 0 || !needed || (n > 0 && (!phi || !expected || !total || !observed)) || (cap > 0 && !buf))
     return ed_fail(ED_ERR_INVALID, "ed_get_loglike_matrix_messages: bad arguments");
   if (int rc = require_device()) return rc;
@@ -2042,12 +2070,13 @@ ED_EXPORT int ed_get_loglike_matrix_messages(const double* phi, const double* ex
   *needed = len;
   return ED_OK;
 }
+ED_CATCH("ed_get_loglike_matrix_messages")
 
 // ---- drop-in 2: C_hmm ----------------------------------------------------------------------
 ED_EXPORT int ed_hmm(int32_t nstates, int32_t nobs, const double* transitions, const double* probabilities,
                      const int32_t* positions, double expected_length, double* path_out, double* calls_out,
                      int64_t calls_cap, int64_t* n_calls)
-{
+try {
   if (nstates != 3) return ed_fail(ED_ERR_INVALID, "ERROR: The code must assume 3 states");  // src/hmm.cpp:37-40
   if (nobs < 0 || calls_cap < 0 || !n_calls || (nobs > 0 && (!transitions || !probabilities || !positions || !path_out)))
     return ed_fail(ED_ERR_INVALID, "ed_hmm: bad arguments");
@@ -2070,12 +2099,13 @@ ED_EXPORT int ed_hmm(int32_t nstates, int32_t nobs, const double* transitions, c
   if (calls_cap > 0) HIP_TRY(hipMemcpy(calls_out, dcalls.p, (size_t)calls_cap * 32, hipMemcpyDeviceToHost));
   return ED_OK;
 }
+ED_CATCH("ed_hmm")
 
 // ---- plan ----------------------------------------------------------------------------------
 ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_t n_chrom, const int32_t* chrom_off,
                              const int32_t* start, const int32_t* end, double transition_probability,
                              double expected_cnv_length)
-{
+try {
   if (!plan || n_exons < 0 || n_chrom < 0 || !chrom_off || (n_exons > 0 && (!start || !end)))
     return ed_fail(ED_ERR_INVALID, "ed_plan_create: bad arguments");
   if (chrom_off[0] != 0 || chrom_off[n_chrom] != n_exons)
@@ -2109,9 +2139,10 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
   {
     // one task per chromosome, spread over the host threads
     unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
-    std::vector<std::thread> pool;
+    ed_thread_pool pool;
     std::vector<char> bad(nt, 0);
     auto work = [&](unsigned tid) {
+      try {
       std::vector<int32_t> pos;
       std::vector<double> lt9;
       for (int c = tid; c < n_chrom; c += nt) {
@@ -2140,11 +2171,12 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
             bad[tid] |= 1;
         }
       }
+      } catch (...) { bad[tid] |= 4; }      // (host memory: nothing may leave a thread's function)
     };
-    for (unsigned tid = 1; tid < nt; ++tid) pool.emplace_back(work, tid);
+    for (unsigned tid = 1; tid < nt; ++tid) pool.start(work, tid);
     work(0);
-    for (auto& th : pool) th.join();
-    for (char b : bad) { if (b & 1) symmetric = false; if (b & 2) out_of_range = true; }
+    pool.join();
+    for (char b : bad) { if (b & 1) symmetric = false; if (b & 2) out_of_range = true; if (b & 4) return ed_fail(ED_ERR_NOMEM, "ed_plan_create: out of host memory"); }
   }
   if (!symmetric)
     return ed_fail(ED_ERR_STATE, "ed_plan_create: internal error, log-transition table is not symmetric");
@@ -2163,6 +2195,7 @@ ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_
   *plan = p;
   return ED_OK;
 }
+ED_CATCH("ed_plan_create")
 
 ED_EXPORT void ed_plan_destroy(ed_plan* p)
 {
@@ -2197,7 +2230,7 @@ static hipError_t ed_stream_create(hipStream_t* st, bool own_queue, int device)
 
 // ---- batch ---------------------------------------------------------------------------------
 ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples)
-{
+try {
   if (!batch || !plan || n_samples <= 0) return ed_fail(ED_ERR_INVALID, "ed_batch_create: bad arguments");
   // k_emit_batch reads the per-sample tables through a buffer resource whose size field is 32 bits: 3 * kEmitTab * n_samples entries
   // of 16 bytes must stay below 2^31 (n_samples <= 43 690), or the entries beyond read as zero
@@ -2349,6 +2382,7 @@ ED_EXPORT int ed_batch_create(ed_batch** batch, ed_plan* plan, int64_t n_samples
   *batch = b;
   return ED_OK;
 }
+ED_CATCH("ed_batch_create")
 
 static void fitwork_free(struct FitWork* w);
 static void binswork_free(void* w);
@@ -2407,7 +2441,7 @@ static int fold_fit_time(ed_batch* b)
 }
 
 ED_EXPORT int ed_batch_enable_timing(ed_batch* b, int enable)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->timing = enable != 0;
   b->have_run_times = b->have_fit_time = false;
@@ -2416,9 +2450,10 @@ ED_EXPORT int ed_batch_enable_timing(ed_batch* b, int enable)
   b->n_runs_timed = b->n_fits_timed = 0;
   return ED_OK;
 }
+ED_CATCH("ed_batch_enable_timing")
 
 ED_EXPORT int ed_batch_set_viterbi_overlap(ed_batch* b, int on)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->overlap_groups = on != 0;
   if (b->overlap_groups) b->group_off = b->group_off_model;
@@ -2428,9 +2463,10 @@ ED_EXPORT int ed_batch_set_viterbi_overlap(ed_batch* b, int on)
   }
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_viterbi_overlap")
 
 ED_EXPORT int ed_batch_set_async_tail(ed_batch* b, int on)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   HIP_TRY(hipSetDevice(b->plan->device));
   if (on && !b->fin) {
@@ -2441,13 +2477,15 @@ ED_EXPORT int ed_batch_set_async_tail(ed_batch* b, int on)
   b->async_tail = on != 0;
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_async_tail")
 
 ED_EXPORT int ed_batch_wait(ed_batch* b, void* stream_)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (b->ran && b->last_run_async && b->done_ev) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, b->done_ev, 0));
   return ED_OK;
 }
+ED_CATCH("ed_batch_wait")
 
 // How the emissions get their per-cell (phi, expected): the default model has one pair per sample; edbins.inc
 // interpolates phi from the reference depth (phi.bins > 1); edcov.inc computes expected = plogis(X beta) per exon.
@@ -2890,9 +2928,10 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
 
 ED_EXPORT int ed_batch_run(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
                            const double* d_expected, double mixture, void* stream_)
-{
+try {
   return batch_run_impl(b, d_test, d_ref, d_phi, d_expected, mixture, stream_, EmitModel());
 }
+ED_CATCH("ed_batch_run")
 
 // workspace of the column-wise beta-binomial fit (shared by ed_batch_fit and ed_select_reference_set)
 struct FitWork {
@@ -2920,10 +2959,16 @@ struct FitWork {
     auto cap_of = [&](int64_t lists) { return std::min<int64_t>(65535 / lists, std::max<int64_t>(8, (E / lists) / 3 + 1)); };
     cap8 = cap_of(hg8::kHistGroups); cap4 = cap_of(hg4::kHistGroups); cap2 = cap_of(hg2::kHistGroups);
     const int64_t slots = std::max({cap8 * hg8::kHistGroups, cap4 * hg4::kHistGroups, cap2 * hg2::kHistGroups});
-    HIP_TRY(hipMalloc((void**)&hist, (size_t)hg2::kHistHalves * hg2::kHistK * hg2::hist_padded(S) * 4));
-    HIP_TRY(hipMalloc((void**)&ov_y, (size_t)slots * S * 4));
-    HIP_TRY(hipMalloc((void**)&ov_r, (size_t)slots * S * 4));
-    HIP_TRY(hipMalloc((void**)&ovn, (size_t)hg2::kHistGroups * S * 4));
+    // all four or none (`hist` is what says "made"): a failed allocation must not leave the sentinel set over missing lists
+    const bool ok = hipMalloc((void**)&hist, (size_t)hg2::kHistHalves * hg2::kHistK * hg2::hist_padded(S) * 4) == hipSuccess &&
+                    hipMalloc((void**)&ov_y, (size_t)slots * S * 4) == hipSuccess && hipMalloc((void**)&ov_r, (size_t)slots * S * 4) == hipSuccess &&
+                    hipMalloc((void**)&ovn, (size_t)hg2::kHistGroups * S * 4) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      void** four[] = {(void**)&hist, (void**)&ov_y, (void**)&ov_r, (void**)&ovn};
+      for (void** q : four) { if (*q) (void)hipFree(*q); *q = nullptr; }
+      return ed_fail(ED_ERR_NOMEM, "beta-binomial fit: cannot allocate the count histograms");
+    }
     return ED_OK;
   }
   int alloc(int64_t E, int64_t S_)
@@ -3075,7 +3120,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
 // i.e. 0-based exons 0, by, 2*by, ... -- a strided view of the count matrices.
 ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, int64_t by, double* d_phi,
                                   double* d_expected, void* stream_)
-{
+try {
   if (!b || !d_test || !d_ref || !d_phi || !d_expected) return ed_fail(ED_ERR_INVALID, "ed_batch_fit: NULL argument");
   hipStream_t st = (hipStream_t)stream_;
   const int64_t E = b->plan->E, S = b->S;
@@ -3099,17 +3144,19 @@ ED_EXPORT int ed_batch_fit_subset(ed_batch* b, const int32_t* d_test, const int3
   b->have_fit_time = b->timing;
   return ED_OK;
 }
+ED_CATCH("ed_batch_fit_subset")
 
 ED_EXPORT int ed_batch_fit(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, double* d_phi, double* d_expected,
                            void* stream_)
-{
+try {
   return ed_batch_fit_subset(b, d_test, d_ref, 1, d_phi, d_expected, stream_);
 }
+ED_CATCH("ed_batch_fit")
 
 // How the last dispersion fit of the batch ended: a sample whose Newton iteration used up its iteration budget without a
 // step below tolerance is reported, not silently returned (aod::betabin exposes optim()'s convergence code likewise).
 ED_EXPORT int ed_batch_fit_n_unconverged(ed_batch* b, int64_t* n_unconverged, int32_t* first_sample)
-{
+try {
   if (!b || !n_unconverged) return ed_fail(ED_ERR_INVALID, "NULL argument");
   if (!b->fitw || !b->fitw->done) return ed_fail(ED_ERR_STATE, "no ed_batch_fit has been issued on this batch");
   HIP_TRY(hipSetDevice(b->plan->device));
@@ -3124,6 +3171,7 @@ ED_EXPORT int ed_batch_fit_n_unconverged(ed_batch* b, int64_t* n_unconverged, in
   if (first_sample) *first_sample = first;
   return ED_OK;
 }
+ED_CATCH("ed_batch_fit_n_unconverged")
 
 ED_EXPORT int64_t ed_batch_n_samples(const ed_batch* b) { return b ? b->S : 0; }
 ED_EXPORT const double* ed_batch_loglik(const ed_batch* b)
@@ -3134,30 +3182,33 @@ ED_EXPORT const double* ed_batch_loglik(const ed_batch* b)
 }
 
 ED_EXPORT int ed_batch_set_fused(ed_batch* b, int fused)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->fused = fused != 0;
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_fused")
 
 ED_EXPORT int ed_batch_set_fit_histograms(ed_batch* b, int on)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (on != 0 && on != 1 && on != 2 && on != 4 && on != 8) return ed_fail(ED_ERR_INVALID, "ed_batch_set_fit_histograms: 0, 1 (automatic), or a geometry 8 / 4 / 2");
   b->fit_hist = on;
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_fit_histograms")
 
 ED_EXPORT int ed_batch_set_fit_mode(ed_batch* b, int mode)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (mode != 0 && mode != 1) return ed_fail(ED_ERR_INVALID, "ed_batch_set_fit_mode: 0 (maximum likelihood) or 1 (aod-nm)");
   b->fit_mode = mode;
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_fit_mode")
 
 ED_EXPORT int ed_batch_set_emit_mode(ed_batch* b, int mode)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (mode != 0 && mode != 1 && mode != 2) return ed_fail(ED_ERR_INVALID, "ed_batch_set_emit_mode: 0 (strict), 1 (tables, exon-major tiles) or 2 (tables, sample-major)");
   if (mode >= 1) {
@@ -3171,18 +3222,20 @@ ED_EXPORT int ed_batch_set_emit_mode(ed_batch* b, int mode)
   b->prepared = false;
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_emit_mode")
 
 ED_EXPORT int ed_batch_set_counts_layout(ed_batch* b, int layout)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (layout != 0 && layout != 1) return ed_fail(ED_ERR_INVALID, "ed_batch_set_counts_layout: 0 ([n_exons][n_samples]) or 1 ([n_samples][n_exons])");
   b->counts_layout = layout;
   b->prepared = false;
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_counts_layout")
 
 ED_EXPORT int ed_batch_set_emit_tables(ed_batch* b, int32_t cap_obs, int32_t cap_ref, double reach)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   if (b->d_tabs) return ed_fail(ED_ERR_STATE, "ed_batch_set_emit_tables: the tables are already allocated (call before ed_batch_set_emit_mode(batch, 1))");
   if (cap_obs < 64 || cap_ref < 64 || cap_obs > (1 << 22) || cap_ref > (1 << 22) || (cap_obs & 7) || (cap_ref & 7) || !(reach >= 1.0 && reach <= 1e6))
@@ -3190,9 +3243,10 @@ ED_EXPORT int ed_batch_set_emit_tables(ed_batch* b, int32_t cap_obs, int32_t cap
   b->tab_capY = cap_obs; b->tab_capR = cap_ref; b->tab_reach = reach;
   return ED_OK;
 }
+ED_CATCH("ed_batch_set_emit_tables")
 
 ED_EXPORT int ed_batch_n_emit_launches(const ed_batch* b)
-{
+try {
   if (!b) return 0;
   if (b->fused) return 1;
   int n = 0;
@@ -3205,14 +3259,16 @@ ED_EXPORT int ed_batch_n_emit_launches(const ed_batch* b)
   if (b->group_off.size() == 2 && b->split_frac > 0.0 && b->split_frac < 1.0 && b->split_ev) n += 1;
   return n;
 }
+ED_CATCH("ed_batch_n_emit_launches")
 
 ED_EXPORT int ed_batch_keep_loglik(ed_batch* b, int keep)
-{
+try {
   if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
   b->keep_loglik = keep != 0;
   if (!b->keep_loglik && b->fused && b->d_loglik) { HIP_TRY(hipFree(b->d_loglik)); b->d_loglik = nullptr; }
   return ED_OK;
 }
+ED_CATCH("ed_batch_keep_loglik")
 ED_EXPORT const uint8_t* ed_batch_path(const ed_batch* b) { return b ? b->d_path : nullptr; }
 ED_EXPORT const ed_call* ed_batch_calls(const ed_batch* b) { return b ? b->d_calls : nullptr; }
 
@@ -3229,7 +3285,7 @@ static int batch_ready(ed_batch* b)
 // to one per exon is possible) gets a table of the right size and the fill kernel is run again -- the records
 // are a pure function of the packed path.
 ED_EXPORT int ed_batch_n_calls(ed_batch* b, int64_t* n_calls)
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!n_calls) return ed_fail(ED_ERR_INVALID, "NULL output");
   if (int rc = ed_d2h(n_calls, b->d_total, 8, b->stream)) return rc;
@@ -3249,9 +3305,10 @@ ED_EXPORT int ed_batch_n_calls(ed_batch* b, int64_t* n_calls)
   }
   return ED_OK;
 }
+ED_CATCH("ed_batch_n_calls")
 
 ED_EXPORT int ed_batch_n_gsl_errors(ed_batch* b, int64_t* n_events)
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!n_events) return ed_fail(ED_ERR_INVALID, "NULL output");
   unsigned long long v = 0;
@@ -3259,9 +3316,10 @@ ED_EXPORT int ed_batch_n_gsl_errors(ed_batch* b, int64_t* n_events)
   *n_events = (int64_t)v;
   return ED_OK;
 }
+ED_CATCH("ed_batch_n_gsl_errors")
 
 ED_EXPORT int ed_batch_copy_calls(ed_batch* b, ed_call* host_calls, int64_t cap)
-{
+try {
   int64_t n = 0;
   if (int rc = ed_batch_n_calls(b, &n)) return rc;   // (grows the table if the run needed more records)
   const int64_t k = std::min(n, cap);
@@ -3271,9 +3329,10 @@ ED_EXPORT int ed_batch_copy_calls(ed_batch* b, ed_call* host_calls, int64_t cap)
   }
   return ED_OK;
 }
+ED_CATCH("ed_batch_copy_calls")
 
 ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int64_t cap)
-{
+try {
   int64_t n = 0;
   if (int rc = ed_batch_n_calls(b, &n)) return rc;   // (grows the table if the run needed more records)
   const int64_t k = std::min(n, cap);
@@ -3295,17 +3354,19 @@ ED_EXPORT int ed_batch_copy_call_info(ed_batch* b, ed_call_info* host_info, int6
   if (int rc = ed_d2h(host_info, b->d_info, (size_t)k * sizeof(ed_call_info), b->stream)) return rc;
   return ED_OK;
 }
+ED_CATCH("ed_batch_copy_call_info")
 
 ED_EXPORT int ed_batch_copy_path(ed_batch* b, uint8_t* host_path)
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!host_path) return ed_fail(ED_ERR_INVALID, "NULL output");
   if (int rc = ed_d2h(host_path, b->d_path, (size_t)b->plan->E * b->S, b->stream)) return rc;
   return ED_OK;
 }
+ED_CATCH("ed_batch_copy_path")
 
 ED_EXPORT int ed_batch_copy_loglik(ed_batch* b, double* host_loglik)
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!host_loglik) return ed_fail(ED_ERR_INVALID, "NULL output");
   if (int rc = ensure_loglik_rows(b)) return rc;
@@ -3314,11 +3375,12 @@ ED_EXPORT int ed_batch_copy_loglik(ed_batch* b, double* host_loglik)
   if (int rc = ed_d2h(host_loglik, b->d_loglik, (size_t)b->plan->E * 3 * b->S * 8, b->stream)) return rc;
   return ED_OK;
 }
+ED_CATCH("ed_batch_copy_loglik")
 
 ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
                                         const double* d_expected, double mixture, int64_t* n_compared, int64_t* n_mismatch,
                                         ed_emit_mismatch* first, int64_t cap)
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!d_test || !d_ref || !d_phi || !d_expected || !n_compared || !n_mismatch || cap < 0 || (cap > 0 && !first))
     return ed_fail(ED_ERR_INVALID, "ed_batch_verify_emissions: bad arguments");
@@ -3346,11 +3408,12 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
   if (k > 0) { if (int rc = ed_d2h(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), b->stream)) return rc; }
   return ED_OK;
 }
+ED_CATCH("ed_batch_verify_emissions")
 
 ED_EXPORT int ed_batch_verify_emissions_tol(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, const double* d_phi,
                                             const double* d_expected, double mixture, double rel_tol, double abs_tol, int64_t* n_compared,
                                             int64_t* n_beyond, double* max_rel, double* max_abs, ed_emit_mismatch* first, int64_t cap)
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!d_test || !d_ref || !d_phi || !d_expected || !n_compared || !n_beyond || cap < 0 || (cap > 0 && !first) || !(rel_tol >= 0) || !(abs_tol >= 0))
     return ed_fail(ED_ERR_INVALID, "ed_batch_verify_emissions_tol: bad arguments");
@@ -3382,10 +3445,11 @@ ED_EXPORT int ed_batch_verify_emissions_tol(ed_batch* b, const int32_t* d_test, 
   if (k > 0) { if (int rc = ed_d2h(first, dfirst.p, (size_t)k * sizeof(ed_emit_mismatch), b->stream)) return rc; }
   return ED_OK;
 }
+ED_CATCH("ed_batch_verify_emissions_tol")
 
 // emit mode 1: one sample's tables as the last run built them (test / diagnostic accessor)
 ED_EXPORT int ed_batch_copy_emit_tables(ed_batch* b, int64_t sample, int32_t dims[2], double* entries, int64_t cap_entries)
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!dims || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_emit_tables: bad arguments");
   if (!b->d_tabs || b->emit_mode < 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_emit_tables: the batch does not run a table-driven emit mode");
@@ -3399,13 +3463,14 @@ ED_EXPORT int ed_batch_copy_emit_tables(ed_batch* b, int64_t sample, int32_t dim
   }
   return ED_OK;
 }
+ED_CATCH("ed_batch_copy_emit_tables")
 
 // table-driven modes: what the last run left to the strict arithmetic
 //   out[0] cells on the strict lists (outside their sample's tables, or under its few-reads rule), summed over the run's launch groups
 //   out[1] samples without tables (walked whole by the strict pass)      out[2] launch groups whose lists ran out (full re-scan)
 //   out[3] cells of the samples without tables
 ED_EXPORT int ed_batch_table_stats(ed_batch* b, int64_t out[4])
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!out) return ed_fail(ED_ERR_INVALID, "NULL output");
   out[0] = out[1] = out[2] = out[3] = 0;
@@ -3415,19 +3480,21 @@ ED_EXPORT int ed_batch_table_stats(ed_batch* b, int64_t out[4])
   out[0] = (int64_t)v[0]; out[1] = (int64_t)v[3]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
   return ED_OK;
 }
+ED_CATCH("ed_batch_table_stats")
 
 ED_EXPORT int ed_batch_n_cold_cells(ed_batch* b, int64_t* n_cells)
-{
+try {
   if (!n_cells) return ed_fail(ED_ERR_INVALID, "NULL output");
   int64_t v[4];
   if (int rc = ed_batch_table_stats(b, v)) return rc;
   *n_cells = v[0];
   return ED_OK;
 }
+ED_CATCH("ed_batch_n_cold_cells")
 
 // one sample's (Ly, Lr, Tm1, reason) of the last run (edtab.inc: tab_dims_of)
 ED_EXPORT int ed_batch_copy_table_dims(ed_batch* b, int64_t sample, int32_t dims[4])
-{
+try {
   if (int rc = batch_ready(b)) return rc;
   if (!dims || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_table_dims: bad arguments");
   if (!b->d_tabs || b->emit_mode < 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_table_dims: the batch does not run a table-driven emit mode");
@@ -3436,9 +3503,10 @@ ED_EXPORT int ed_batch_copy_table_dims(ed_batch* b, int64_t sample, int32_t dims
   dims[0] = d.x; dims[1] = d.y; dims[2] = d.z; dims[3] = d.w;
   return ED_OK;
 }
+ED_CATCH("ed_batch_copy_table_dims")
 
 ED_EXPORT int ed_batch_stage_ms_total(ed_batch* b, double ms_total[5], int64_t* n_runs, int64_t* n_fits)
-{
+try {
   if (!b || !ms_total) return ed_fail(ED_ERR_INVALID, "NULL argument");
   if (int rc = fold_run_times(b)) return rc;
   if (int rc = fold_fit_time(b)) return rc;
@@ -3447,15 +3515,17 @@ ED_EXPORT int ed_batch_stage_ms_total(ed_batch* b, double ms_total[5], int64_t* 
   if (n_fits) *n_fits = b->n_fits_timed;
   return ED_OK;
 }
+ED_CATCH("ed_batch_stage_ms_total")
 
 ED_EXPORT int ed_batch_stage_ms(ed_batch* b, float ms[5])
-{
+try {
   if (!b || !ms) return ed_fail(ED_ERR_INVALID, "NULL argument");
   if (int rc = fold_run_times(b)) return rc;     // (a pending pair of events becomes the "last" value)
   if (int rc = fold_fit_time(b)) return rc;
   for (int i = 0; i < 5; ++i) ms[i] = b->last_ms[i];
   return ED_OK;
 }
+ED_CATCH("ed_batch_stage_ms")
 
 #include "edrefset.inc"
 #include "edbins.inc"
