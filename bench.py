@@ -840,31 +840,41 @@ def main():
             alone_ms = bb.stage_ms()["emissions"]
 
     # ---- after the timed region: the bench checks what it timed, and carries the legs the headline does not -----------------
+    # A leg that fails on ONE rank must not cost the line its headline (measured above): it reports {"error": ...} instead.  (With several
+    # ranks a leg holds collectives -- a rank that skipped the rest of it would leave the others waiting -- so there a failure stays fatal.)
+    def leg(fn, *a, **k):
+        if world > 1:
+            return fn(*a, **k)
+        try:
+            return fn(*a, **k)
+        except Exception as e:          # noqa: BLE001
+            import traceback
+            return {"error": "%s: %s" % (type(e).__name__, e), "where": traceback.format_exc().strip().splitlines()[-3:]}
     verify = None
     if world == 1 and args.verify_columns > 0 and plain and not args.fused:      # (N = 1 only, like cpu_baseline: the other ranks would wait)
-        verify = verify_against_oracle(ed, eddist, torch, dev, co if use_cohort else None, batches, last_ticket[0] if use_cohort else None,
+        verify = leg(verify_against_oracle, ed, eddist, torch, dev, co if use_cohort else None, batches, last_ticket[0] if use_cohort else None,
                                        n_batches, test, ref, phi, p, phi_fit if not use_cohort else None, p_fit if not use_cohort else None,
                                        bool(args.fit), chrom_off, start, end, args.verify_columns, tables=args.emit_mode != "strict")
     fit_conc = None
     if world == 1 and args.fit and plain and not args.fused and args.fit_concordance > 0:
         from exomedepth_amd import concordance
         k = min(args.fit_concordance, S)
-        fit_conc = concordance.fit_mode_concordance(plan, test[:, :k].contiguous(), ref[:, :k].contiguous())
+        fit_conc = leg(concordance.fit_mode_concordance, plan, test[:, :k].contiguous(), ref[:, :k].contiguous())
     config1 = None
     if world == 1 and args.config1_steps > 0 and plain and not args.fused and S >= 64:
-        config1 = config1_leg(ed, torch, plan, test, ref, phi, p, E, args.config1_steps, mode_opts(args))
+        config1 = leg(config1_leg, ed, torch, plan, test, ref, phi, p, E, args.config1_steps, mode_opts(args))
     staged = None
     if world == 1 and args.stage_inputs and use_cohort:
-        staged = staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
+        staged = leg(staged_leg, ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
     workflow = None
     if args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64 and (world == 1 or use_pg):
-        workflow = workflow_leg(ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode], world, rank, eddist)
+        workflow = leg(workflow_leg, ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode], world, rank, eddist)
     other_modes = None
     if world == 1 and args.strict_steps > 0 and plain and not args.fused and use_cohort and args.emit_mode == "tables":
-        other_modes = {"strict": mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {}),
-                       "fit_mode_1": (mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, True, phi, p, {**mode_opts(args), "fit_mode": 1})
+        other_modes = {"strict": leg(mode_leg, ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {}),
+                       "fit_mode_1": (leg(mode_leg, ed, torch, plan, test, ref, S, args.strict_steps, True, phi, p, {**mode_opts(args), "fit_mode": 1})
                                       if args.fit and args.fit_mode == 0 else None),
-                       "tables_counts_exons_x_samples": mode_leg(ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {"emit_mode": 2}),
+                       "tables_counts_exons_x_samples": leg(mode_leg, ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {"emit_mode": 2}),
                        "note": "the same workload and pipeline, after the timed region: strict = emit mode 0 (GSL's arithmetic operation for operation, "
                                "bit-identical to the checker: rounds 1-3's headline); fit_mode_1 = the headline's mode with the dispersion fit by "
                                "aod::betabin's Nelder-Mead procedure (--fit-mode 1) instead of Newton's method; tables_counts_exons_x_samples = the headline's mode handed "
@@ -927,16 +937,18 @@ def main():
             "extra": {"config1": config1, "workflow": workflow, "other_modes": other_modes},
         }
         if staged:
-            out["value_with_h2d"] = staged.pop("value_with_h2d")
+            if "value_with_h2d" in staged:
+                out["value_with_h2d"] = staged.pop("value_with_h2d")
             out["h2d"] = staged
         if world == 1 and args.cpu_samples > 0:
             k = min(args.cpu_samples, S)
             ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(test[:, :k].cpu().numpy(), ref[:, :k].cpu().numpy(),
-                                               p[:k].cpu().numpy(), phi[:k].cpu().numpy(), chrom_off, start, end, bool(args.fit),
-                                               allcores=ncores if args.cpu_all_cores else 0)
-            out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
-            out["speedup_vs_cpu_1core_without_fit_standin"] = value / out["cpu_baseline"]["value_without_fit"]
+            out["cpu_baseline"] = leg(cpu_baseline, test[:, :k].cpu().numpy(), ref[:, :k].cpu().numpy(),
+                                      p[:k].cpu().numpy(), phi[:k].cpu().numpy(), chrom_off, start, end, bool(args.fit),
+                                      allcores=ncores if args.cpu_all_cores else 0)
+            if "error" not in out["cpu_baseline"]:
+                out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
+                out["speedup_vs_cpu_1core_without_fit_standin"] = value / out["cpu_baseline"]["value_without_fit"]
         print(json.dumps(out))
     for b in batches:
         b.close()

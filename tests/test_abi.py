@@ -53,3 +53,31 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|libed_oracle|edoracle|#include\s+[\"<][^\n]*oracle", t, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_no_exception_can_leave_an_entry_point():
+    """The callers are C (R's .Call, ctypes): every int-returning export of the library is a function-try-block closed by ED_CATCH
+    (csrc/edcore.hip::ed_caught turns what was thrown into an error code + ed_last_error()).  One-line accessors hold nothing that throws."""
+    csrc = os.path.join(ROOT, "exomedepth_amd", "csrc")
+    n = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".inc")):
+            continue
+        lines = open(os.path.join(csrc, f)).read().split("\n")
+        for i, l in enumerate(lines):
+            if not l.startswith("ED_EXPORT int "):
+                continue
+            if l.rstrip().endswith("}") and "{" in l:
+                assert "std::" not in l and "new " not in l, (f, i + 1)
+                continue
+            j = i
+            while not lines[j].startswith(("{", "try {")):
+                j += 1
+            name = re.match(r"ED_EXPORT int (\w+)\(", l).group(1)
+            assert lines[j] == "try {", "%s:%d %s is not a function-try-block" % (f, i + 1, name)
+            k = j + 1
+            while lines[k] != "}":
+                k += 1
+            assert lines[k + 1] == 'ED_CATCH("%s")' % name, "%s:%d %s" % (f, k + 2, name)
+            n += 1
+    assert n >= 90
