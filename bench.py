@@ -393,6 +393,45 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
             for k, v in zip(("upload_ms", "reference_sets_ms", "calls_ms", "total_ms"), (t1 - t0, t2 - t1, t3 - t2, t3 - t0)):
                 times[k].append(v * 1e3)
         del rs
+    # Cohorts back to back (one rank): the NEXT cohort's counts cross the link on a copy stream while this one's reference sets and calls run --
+    # what a caller with more than one cohort to process gets per cohort (the link is idle for 3/4 of the serial form above).
+    back_to_back = None
+    if world == 1 and reps > 0:
+        cs, ws = torch.cuda.Stream(), torch.cuda.Stream()     # copy stream; the stream the reference-set stage works on (the null stream would order it behind the copy)
+
+        import threading
+
+        class Upload(threading.Thread):       # (torch does not know the library's pinned block as pinned and makes the issuing thread wait for the copy: a thread of its own)
+            def run(self):
+                torch.cuda.set_device(test.device)
+                with torch.cuda.stream(cs):
+                    self.d = torch.from_numpy(pin.array.view(np.int16)).to(test.device, non_blocking=True).view(torch.int16).to(torch.int32) & 0xffff
+                    cs.synchronize()
+
+        def upload_async():
+            u = Upload()
+            u.start()
+            return u
+        n_coh = 2 * reps
+        nxt = upload_async()
+        nxt.join()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_coh):
+            nxt.join()                        # (the library's streams are its own: the host orders them behind the copy)
+            d = nxt.d
+            nxt = upload_async()              # cohort k + 1 (after the last one: one more, so that every timed cohort carries an upload beside it)
+            rs = ed.cohort_select_reference_sets(d, bl, 10000, max_refs=32, reference_out=ref_t, sample_major=sm, counts_sm_out=counts_sm, stream=ws.cuda_stream)
+            tk = co.submit(counts_sm if sm else d, ref_t, n_samples=S, ready_stream=ws.cuda_stream)
+            co.wait(tk)
+            assert co.batch(tk)[0].n_calls() == n_calls
+            del rs, d
+        t1 = time.perf_counter()
+        nxt.join()
+        back_to_back = {"cohorts": n_coh, "ms_per_cohort": (t1 - t0) / n_coh * 1e3, "value": E * S / ((t1 - t0) / n_coh), "unit": "exons*samples/s",
+                        "note": "the same cohort %d times in a row, the next one's upload (pinned uint16 -> device, widened there) issued on a copy stream before "
+                                "this one's reference sets start; same call count every time" % n_coh}
+        del nxt
     co.close(); pin.free()
     med = {k: float(np.median(v)) for k, v in times.items()}
     return {"workload": "one cohort of %d samples x %d exons: counts from pinned host memory (uint16) -> reference sets of every sample against all "
@@ -400,7 +439,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
                         "when the calls run in the sample-major table mode on one rank) -> fit + emissions + Viterbi + calls; "
                         "stages one after the other (one cohort, nothing to overlap with), median of %d" % (S, E, reps),
             **med, "value": E * S * world / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls, "table_stats": tstats,
-            "ranks": world, "choice_checksum_rank0": checksum,
+            "ranks": world, "choice_checksum_rank0": checksum, "back_to_back": back_to_back,
             "sharding": (None if world == 1 else "every rank: its own %d columns as tests, all %d as candidates (one all_gather of the count slabs); "
                                                   "times and counts are rank 0's" % (S, S * world))}
 

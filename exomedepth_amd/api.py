@@ -1047,7 +1047,7 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
 
 
 def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_refs=32, want_reference=True, want_correlations=False,
-                                 reference_out=None, test_range=None, sample_major=False, counts_sm_out=None):
+                                 reference_out=None, test_range=None, sample_major=False, counts_sm_out=None, stream=None):
     """select.reference.set for every sample of a cohort against all the others (reference vignette/vignette.Rnw:390-402 loop;
     R/optimize_reference_set.R:53-148 per sample), in one call.
 
@@ -1057,7 +1057,10 @@ def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_
     cohort; the per-test outputs then have t1 - t0 rows / columns (ed_cohort_select_reference_sets_range).
     sample_major=True: the aggregate references come back sample-major, (n_tests, E) -- R's column-major matrix, what Cohort(emit_mode=2,
     counts_layout=1) takes -- and counts_sm_out (an (S, E) int32 device array), when given, receives the count matrix transposed alongside
-    (ed_cohort_select_reference_sets_sm)."""
+    (ed_cohort_select_reference_sets_sm).
+    stream: the HIP stream (its handle as an integer, e.g. torch.cuda.Stream().cuda_stream) the entry's kernels and copies are issued on; None =
+    the null stream, which is ordered against every blocking stream of the process -- a caller that wants a copy on another stream to run
+    beside this call names a stream of its own here.  The entry returns when its work is complete either way."""
     keep = []
     E, S = int(counts.shape[0]), int(counts.shape[1])
     t0, t1 = (0, S) if test_range is None else (int(test_range[0]), int(test_range[1]))
@@ -1084,11 +1087,11 @@ def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_
         cs_ptr = _device_pointer(counts_sm_out, np.int32, keep) if counts_sm_out is not None else None
         check(lib().ed_cohort_select_reference_sets_sm(pc, E, S, _ptr(bl) if bl is not None else None, int(n_bins_reduced), K, t0, t1,
                                                        _ptr(n_chosen), _ptr(choice), _ptr(rows), _ptr(corr) if corr is not None else None,
-                                                       ref_ptr, cs_ptr, C.byref(nsel), None))
+                                                       ref_ptr, cs_ptr, C.byref(nsel), C.c_void_p(stream or 0)))
     else:
         check(lib().ed_cohort_select_reference_sets_range(pc, E, S, _ptr(bl) if bl is not None else None, int(n_bins_reduced), K, t0, t1,
                                                           _ptr(n_chosen), _ptr(choice), _ptr(rows), _ptr(corr) if corr is not None else None,
-                                                          ref_ptr, C.byref(nsel), None))
+                                                          ref_ptr, C.byref(nsel), C.c_void_p(stream or 0)))
     out = {"n_chosen": n_chosen, "choice": choice, "summary.stats": rows, "n.bins": int(nsel.value)}
     if ref is not None:
         out["reference"] = ref
