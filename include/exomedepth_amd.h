@@ -402,7 +402,11 @@ int ed_refset_thin_positions(int64_t len, int64_t n_reduced, int64_t* positions,
  *   d_ref_out  DEVICE (optional) int32 [n_bins][n_samples]: aggregate reference = sum of the chosen columns (vignette.Rnw:398-402),
  *              what ed_batch_run / ed_cohort_submit take as d_ref next to d_test = d_counts
  * The S x S correlations are one binary64 Gram matrix on the matrix cores (v_mfma_f64_16x16x4_f64); the K x n_samples cumulative
- * references are fitted as one batch.  Synchronous. */
+ * references are fitted as one batch.  Synchronous.
+ *   stream     the HIP stream (hipStream_t) the entry issues its kernels and transfers on; NULL = the null stream, which is ordered against
+ *              every blocking stream of the process -- name a stream of your own to let a copy on another stream (the next cohort's counts)
+ *              run beside the call.  The entry's ~25 small host <-> device transfers do not use the DMA queues (a pinned block and a copy
+ *              kernel), so they do not wait behind such a copy either.  d_counts must be complete on `stream` when the call is made. */
 int ed_cohort_select_reference_sets(const int32_t* d_counts, int64_t n_bins, int64_t n_samples, const double* bin_length,
                                     int64_t n_bins_reduced, int32_t max_refs, int32_t* n_chosen, int32_t* choice, ed_refset_row* rows,
                                     double* correlations, int32_t* d_ref_out, int64_t* n_selected_bins, void* stream);
