@@ -1047,7 +1047,7 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
 
 
 def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_refs=32, want_reference=True, want_correlations=False,
-                                 reference_out=None, test_range=None, sample_major=False, counts_sm_out=None, stream=None):
+                                 reference_out=None, test_range=None, sample_major=False, counts_sm_out=None, stream=None, grow_max_refs=True):
     """select.reference.set for every sample of a cohort against all the others (reference vignette/vignette.Rnw:390-402 loop;
     R/optimize_reference_set.R:53-148 per sample), in one call.
 
@@ -1060,7 +1060,20 @@ def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_
     (ed_cohort_select_reference_sets_sm).
     stream: the HIP stream (its handle as an integer, e.g. torch.cuda.Stream().cuda_stream) the entry's kernels and copies are issued on; None =
     the null stream, which is ordered against every blocking stream of the process -- a caller that wants a copy on another stream to run
-    beside this call names a stream of its own here.  The entry returns when its work is complete either way."""
+    beside this call names a stream of its own here.  The entry returns when its work is complete either way.
+    grow_max_refs: a test whose choice is LONGER than max_refs is an error of the C entry ("call again with a larger max_refs": its outputs
+    have max_refs columns); True = this wrapper does that, doubling max_refs until every choice fits (the result never depends on
+    max_refs otherwise).  With thousands of candidates (a rank of a sample-sharded cohort: 8 191 of them) choices of 33 - 35 do occur."""
+    if grow_max_refs:
+        k = int(max_refs if max_refs > 0 else 32)
+        while True:
+            try:
+                return cohort_select_reference_sets(counts, bin_length, n_bins_reduced, k, want_reference, want_correlations, reference_out, test_range,
+                                                    sample_major, counts_sm_out, stream, grow_max_refs=False)
+            except EdError as e:
+                if "larger max_refs" not in str(e) or k >= int(counts.shape[1]) - 1:
+                    raise
+                k = min(2 * k, int(counts.shape[1]) - 1)
     keep = []
     E, S = int(counts.shape[0]), int(counts.shape[1])
     t0, t1 = (0, S) if test_range is None else (int(test_range[0]), int(test_range[1]))

@@ -23,6 +23,7 @@
 #include <R_ext/Rdynload.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "exomedepth_amd.h"
 
@@ -326,9 +327,17 @@ SEXP edr_cohort_reference_sets(SEXP counts, SEXP bin_length, SEXP n_bins_reduced
   SEXP nb = allocVector(REALSXP, 1); SET_VECTOR_ELT(out, 4, nb);
   int64_t nsel = 0;
   /* choice comes back [n_samples][K] row-major = the K x n_samples matrix column-major; correlations are symmetric */
-  const int rc = ed_cohort_select_reference_sets_host(INTEGER(counts), E, S, bin_length != R_NilValue ? REAL(bin_length) : NULL,
-                                                      (int64_t)INTEGER(n_bins_reduced)[0], K, INTEGER(nch), INTEGER(cho), NULL, REAL(cor),
-                                                      INTEGER(ref), &nsel);
+  int rc;
+  for (;;) {
+    rc = ed_cohort_select_reference_sets_host(INTEGER(counts), E, S, bin_length != R_NilValue ? REAL(bin_length) : NULL,
+                                              (int64_t)INTEGER(n_bins_reduced)[0], K, INTEGER(nch), INTEGER(cho), NULL, REAL(cor),
+                                              INTEGER(ref), &nsel);
+    /* a choice longer than max.refs: the library asks for a larger one (its outputs have max.refs columns; the result does not depend
+       on it otherwise) -- done here, so that the R caller never sees a limit the reference does not have */
+    if (rc == ED_OK || K >= S - 1 || strstr(ed_last_error(), "larger max_refs") == NULL) break;
+    K = (2 * K < S - 1) ? 2 * K : S - 1;
+    cho = allocMatrix(INTSXP, K, S); SET_VECTOR_ELT(out, 1, cho);
+  }
   if (rc != ED_OK) {
     UNPROTECT(1);
     Rf_error("exomedepth_amd: %s", ed_last_error());

@@ -68,7 +68,12 @@ def test_a_short_max_refs_falls_back_instead_of_changing_the_answer(edlib):
             assert np.array_equal(short["choice"][t, :short["n_chosen"][t]], full["choice"][t, :full["n_chosen"][t]])
     else:
         with pytest.raises(edlib.EdError, match="larger max_refs"):
-            edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=3, want_reference=False)
+            edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=3, want_reference=False, grow_max_refs=False)
+        # ... and the wrapper's default does what the message says: max_refs doubled until every choice fits, the same answer
+        grown = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=3, want_reference=False)
+        assert grown["choice"].shape[1] > 3 and np.array_equal(grown["n_chosen"], full["n_chosen"])
+        for t in range(24):
+            assert np.array_equal(grown["choice"][t, :grown["n_chosen"][t]], full["choice"][t, :full["n_chosen"][t]])
 
 
 def test_cohort_selection_feeds_the_cohort_pipeline(edlib):
@@ -127,6 +132,31 @@ def test_config4_geometry_every_sample_against_all_others_500k_x_2048(edlib):
         assert [int(v) for v in res["choice"][t, :res["n_chosen"][t]]] == want
         assert torch.equal(agg[:, t], counts[:, want].sum(dim=1).to(torch.int32))
         del others
+
+
+def test_one_rank_of_eight_200k_x_8192(edlib):
+    """What every rank of `bench.py --gpus 8` runs in its workflow leg after the all-gather of the count slabs (BASELINE configs[3]'s cohort): 200 000 bins x
+    8 192 samples on the device, the rank's own 1 024 samples as tests, all 8 192 as candidates.  The last rank's share; spot tests against the single-test
+    entry (same columns, same order) and the aggregate reference against the column sums."""
+    torch = pytest.importorskip("torch")
+    from exomedepth_amd import synth, dist as eddist
+    E, S, W, rank = 200_000, 1024, 8, 7
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(20250623)            # (synth draws its beta variates from torch's global generator)
+    chrom_off, start, end = synth.exon_design(E, 24, seed=20250620)
+    counts = torch.cat([synth.counts_torch(chrom_off, S, dev, seed=20250623 + r, mean_depth=100.0)[0] for r in range(W)], dim=1).contiguous()
+    bl = (np.asarray(end) - np.asarray(start)) / 1000.0
+    res = edlib.cohort_select_reference_sets(counts, bl, 10000, max_refs=32, test_range=(rank * S, (rank + 1) * S))
+    # (with 8 191 candidates a choice of 33 - 35 references does occur: the wrapper then doubles max_refs, as the C entry's message asks)
+    assert res["n.bins"] in (10000, 10001) and np.all(res["n_chosen"] >= 1) and np.all(res["n_chosen"] <= res["choice"].shape[1])
+    agg = torch.as_tensor(eddist._DevicePointer(res["reference"].ptr.value, (E, S), "<i4"), device=dev)
+    for t in (rank * S + 517, rank * S + int(np.argmax(res["n_chosen"])), (rank + 1) * S - 1):
+        keep = [c for c in range(S * W) if c != t]
+        one = edlib.select_reference_set(counts[:, t].contiguous(), counts[:, keep].contiguous(), bl, 10000, names=[str(c) for c in keep])
+        want = [int(c) for c in one["reference.choice"]]
+        tl = t - rank * S
+        assert [int(v) for v in res["choice"][tl, :res["n_chosen"][tl]]] == want
+        assert torch.equal(agg[:, tl], counts[:, want].sum(dim=1).to(torch.int32))
 
 
 def test_test_ranges_are_the_rows_of_the_whole_cohort_call(edlib):
