@@ -362,7 +362,11 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
     stream = torch.cuda.current_stream()
     times = {"upload_ms": [], "reference_sets_ms": [], "calls_ms": [], "total_ms": []}
     n_calls = n_chosen = None
-    sm = emit_mode == 2 and world == 1 and S <= 4096     # sample-major hand-over: aggregate references and the transposed counts straight from the reference-set stage
+    # (a process group of ONE rank -- ED_BENCH_FORCE_PG=1 on a 1-GPU box -- takes the sharded path too: RCCL's all_gather_into_tensor on device memory, the
+    #  branch no two-ranks-on-one-GPU run can reach, since RCCL refuses two ranks on one device)
+    import torch.distributed as tdist
+    sharded = world > 1 or (eddist is not None and tdist.is_available() and tdist.is_initialized())
+    sm = emit_mode == 2 and not sharded and S <= 4096     # sample-major hand-over: aggregate references and the transposed counts straight from the reference-set stage
     co = ed.Cohort(plan, S, 1, **({"emit_mode": emit_mode, "counts_layout": 1 if sm else 0} if emit_mode else {}))
     ref_t = torch.empty((S, E) if sm else (E, S), dtype=torch.int32, device=test.device)
     counts_sm = torch.empty((S, E), dtype=torch.int32, device=test.device) if sm else None
@@ -372,7 +376,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
         dcounts = torch.from_numpy(pin.array.view(np.int16)).to(test.device, non_blocking=True).view(torch.int16).to(torch.int32) & 0xffff
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        if world > 1:
+        if sharded:
             # a sample-sharded cohort: this rank's columns are S of world * S; every other rank's samples are candidates too -- one
             # all_gather of the count slabs, then the rank's own tests (exomedepth_amd/dist.py::cohort_reference_sets_sharded)
             rs = eddist.cohort_reference_sets_sharded(dcounts, S * world, bl, 10000, max_refs=32)
@@ -396,7 +400,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
     # Cohorts back to back (one rank): the NEXT cohort's counts cross the link on a copy stream while this one's reference sets and calls run --
     # what a caller with more than one cohort to process gets per cohort (the link is idle for 3/4 of the serial form above).
     back_to_back = None
-    if world == 1 and reps > 0:
+    if not sharded and reps > 0:
         cs, ws = torch.cuda.Stream(), torch.cuda.Stream()     # copy stream; the stream the reference-set stage works on (the null stream would order it behind the copy)
 
         import threading
@@ -440,7 +444,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
                         "stages one after the other (one cohort, nothing to overlap with), median of %d" % (S, E, reps),
             **med, "value": E * S * world / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls, "table_stats": tstats,
             "ranks": world, "choice_checksum_rank0": checksum, "back_to_back": back_to_back,
-            "sharding": (None if world == 1 else "every rank: its own %d columns as tests, all %d as candidates (one all_gather of the count slabs); "
+            "sharding": (None if not sharded else "every rank: its own %d columns as tests, all %d as candidates (one all_gather of the count slabs); "
                                                   "times and counts are rank 0's" % (S, S * world))}
 
 

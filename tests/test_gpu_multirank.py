@@ -59,3 +59,26 @@ def test_two_ranks_share_one_gpu_and_gather_their_call_tables(edlib):
     ch = rs["choice"][:S]
     assert w["choice_checksum_rank0"] == int(np.sum((ch.astype(np.int64) + 1) * (np.arange(ch.shape[1], dtype=np.int64) + 1)[None, :]))
     assert abs(w["references_chosen_mean"] - float(rs["n_chosen"][:S].mean())) < 1e-12
+
+
+def test_one_rank_over_rccl(edlib):
+    """A process group of ONE rank over RCCL on the box's GPU (ED_BENCH_FORCE_PG=1): the collectives of the N > 1 path as RCCL runs them -- barrier, the
+    MAX all-reduce of the clock, the gather of the call tables from DEVICE memory, and the workflow leg's all_gather_into_tensor of the count slabs -- the
+    branches the two-ranks-on-one-GPU test (gloo, host memory) cannot reach.  Same calls, same reference choices as the run without a group."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--exons", "20000", "--samples", "128",
+            "--cpu-samples", "0", "--verify-columns", "0", "--fit-concordance", "0", "--config1-steps", "0", "--kernel-alone", "0", "--stage-inputs", "0",
+            "--strict-steps", "0", "--workflow-reps", "1"]
+    out = {}
+    for name, extra in (("plain", {}), ("rccl", {"ED_BENCH_FORCE_PG": "1", "MASTER_PORT": "29647"})):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        r = subprocess.run(base, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out[name] = json.loads(lines[0])
+    a, b = out["plain"], out["rccl"]
+    assert b["n_gpus"] == 1 and b["n_calls"] == a["n_calls"] > 0
+    wa, wb = a["extra"]["workflow"], b["extra"]["workflow"]
+    assert wa["sharding"] is None and wb["sharding"] is not None            # the group's run went through dist.cohort_reference_sets_sharded
+    assert wb["choice_checksum_rank0"] == wa["choice_checksum_rank0"] and wb["n_calls"] == wa["n_calls"] > 0
+    assert abs(wb["references_chosen_mean"] - wa["references_chosen_mean"]) < 1e-12
