@@ -643,10 +643,24 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # stdout carries ONE line, the JSON record.  With NCCL_DEBUG=VERSION (the GPU boxes export it) RCCL printf()s a five-line banner to stdout when its
+        # communicator is made; NCCL_DEBUG_FILE does not move it.  So file descriptor 1 points at stderr while the group and its communicator come up
+        # (the first collective), the C library's buffers are flushed there, and stdout is put back: the banner lands next to the other diagnostics.
+        import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+            torch.cuda.synchronize()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     # The process group is initialised AFTER the pipeline's streams have been used once (below): hardware queues are handed to
     # streams in order of first use, and RCCL takes one when it starts -- which would shift the stream-to-queue mapping of
