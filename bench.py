@@ -385,7 +385,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
             rs = ed.cohort_select_reference_sets(dcounts, bl, 10000, max_refs=32, reference_out=ref_t, sample_major=sm, counts_sm_out=counts_sm)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        tk = co.submit(counts_sm if sm else dcounts, ref_t, n_samples=S)     # (two half-cohort slabs through the pipeline were tried: 17 ms against 12.7 -- the slicing copies cost more than the overlap gives)
+        tk = co.submit(counts_sm if sm else dcounts, ref_t, n_samples=S)     # (two half-cohort slabs through the pipeline were tried: 17 ms against 12.7 in the [exons][samples] layout, where the cut costs strided copies -- and, round 5, in the sample-major layout where it is free: 8.6 ms as two slabs, 10.7 as four, against 7.5 as one: every slab pays its own longest chain)
         co.wait(tk)
         b, _, _ = co.batch(tk)
         n_calls = b.n_calls()
