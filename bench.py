@@ -241,12 +241,12 @@ NOTE_STRICT = ("FP64-VALU-bound kernel (no MFMA applies; SURVEY.md 0.5): the HBM
                "run on, averaged over the timed steps; consecutive batches' emissions are back to back on that stream.  "
                "Traffic above 9 B/cell: the kernel materialises the [E][3][S] f64 likelihood matrix (the reference's S4 "
                "`likelihood` slot: 33 B/cell algorithmic in that form, SURVEY.md 8d) and gathers per-sample tables")
-NOTE_TABLES = ("table-driven emissions, sample-major (k_emit_tab_sm): ~110 VALU lane-instructions per cell, the hot 85-99 % of a sample's "
+NOTE_TABLES = ("table-driven emissions, sample-major (k_emit_tab_sm): ~155 VALU lane-instructions per cell, the hot 85-99 % of a sample's "
                "log-gamma difference tables in LDS -- a memory-streaming kernel: reads the counts (8 B/cell) and writes the [S][3][E] f64 "
                "likelihood matrix (24 B/cell) that k_viterbi_sm reads back, i.e. 33 B/cell algorithmic in the materialised form against the "
                "9 B/cell of `achieved` (SURVEY.md 8d).  kernel_ms: HIP events recorded by the library around the emission launches on the "
-               "stream they run on (two launches per step: the cut the next slab's fit is issued at), live = sharing the chip with the "
-               "previous slab's Viterbi chains and the next slab's fit; kernel_ms_alone = the same launches with the GPU to themselves")
+               "stream they run on (one launch per step), live = sharing the chip with the previous slab's Viterbi chains, the next slab's fit and -- with "
+               "two lanes, the default -- the OTHER lane's emission launch (roofline.launch_overlap); kernel_ms_alone = the same launch with the GPU to itself")
 
 
 def mode_opts(args):
@@ -597,7 +597,9 @@ def main():
     ap.add_argument("--config1-steps", type=int, default=20, help="timed steps of the BASELINE configs[1] leg (200 000 x 64, phi given) run after "
                     "the headline and reported under extra.config1 (0 = skip)")
     ap.add_argument("--verify-columns", type=int, default=4, help="columns of the last slabs checked against the CPU oracle after the timed region (0 = skip)")
-    ap.add_argument("--batches-in-flight", type=int, default=2, help="batch objects used in rotation by the pipelined schedule (>= 2)")
+    ap.add_argument("--batches-in-flight", type=int, default=4, help="slabs in flight in the library's cohort pipeline = batch objects used in rotation (>= 2).  "
+                    "4 (default): two LANES of two slots -- independent pipelines inside the cohort object, one lane's emission launch fills the CUs that "
+                    "the other's table build and chains leave idle (3.77 against 4.11 ms per step with 2 = one lane; 6: 3.81-3.96; 8: 4.2)")
     ap.add_argument("--workflow-reps", type=int, default=3, help="after the timed region (N = 1): the reference's workflow for one cohort end to end -- "
                     "upload, reference sets, calls -- reported under extra.workflow; 0: skip")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
@@ -977,6 +979,15 @@ def main():
                          "frac_with_likelihood_matrix": (33 * E * S / t_emit / 1e9 / HBM_PEAK_GBS) if t_emit > 0 else None,
                          "frac_alone_with_likelihood_matrix": (33 * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "kernel_ms_alone": alone_ms,
+                         "launch_overlap": {"lanes": (n_batches // 2 if (use_cohort and n_batches in (4, 6, 8)) else 1),
+                                            "from_profile": (meta.get("emission_overlap") if meta else None),
+                                            "frac_union": ((ALGO_BYTES_PER_CELL * E * S / n_launch / (meta["emission_overlap"]["union_ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                                           if meta and meta.get("emission_overlap") else None),
+                                            "frac_step": ALGO_BYTES_PER_CELL * E * S / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                            "note": "with more than one lane the emission launches of consecutive slabs run side by side: `achieved` / `frac` divide a launch's "
+                                                    "bytes by ITS duration (what the contract asks for), during which it shares the chip with another emission launch most of the "
+                                                    "time -- kernel_ms_per_step exceeds ms_per_step.  frac_union divides by the union of the launches' intervals per launch "
+                                                    "(kernel trace of the matching profile), frac_step by the whole step, frac_alone by the launch with the chip to itself"},
                          "frac_alone": (ALGO_BYTES_PER_CELL * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "valu": pmc if pmc else why_not,
                          "note": (NOTE_TABLES if args.emit_mode == "tables" and plain else NOTE_STRICT)},

@@ -72,6 +72,13 @@ static int ed_fail(int code, const char* fmt, ...)
   return code;
 }
 
+// hipMemset() on device memory is a NULL-STREAM operation that may return before it has run.  A buffer initialised that way and used next on a
+// hipStreamNonBlocking stream (the pipeline's streams with option own_queues = 0, or a caller's) is not ordered behind the fill: found as a fit that
+// started from poisoned partial sums (tests/test_gpu_cohort.py, six slabs in flight, own_queues = 0, torch's HIP runtime in the process: results equal
+// to 1e-15 instead of bit for bit) -- the workspace's all-ones fill landed after the first pass had written its sums.  Every one-time initialisation by
+// hipMemset is therefore followed by this fence before the buffer is handed to a stream.
+static hipError_t ed_null_stream_fence() { return hipStreamSynchronize(nullptr); }
+
 // No C++ exception leaves the library: the callers are C (R's .Call, ctypes).  Every int-returning entry point is a function-try-block
 // closed by ED_CATCH, which turns what was thrown (in practice std::bad_alloc from a host container, std::system_error from a
 // thread that could not be started) into an error code + ed_last_error().
@@ -2561,6 +2568,7 @@ static int tab_setup(ed_batch* b)
   if (ok && hipMemset(b->d_tdims, 0, (size_t)(S + 64) * 16) != hipSuccess) ok = false;
   if (ok && hipMemset(b->d_notab, 0, (size_t)(S + 1) * 4) != hipSuccess) ok = false;
   if (ok && hipMemcpy(b->d_seg_t, b->seg_t.data(), b->seg_t.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+  if (ok && ed_null_stream_fence() != hipSuccess) ok = false;
   if (!ok) {
     tab_release(b);
     return ed_fail(ED_ERR_NOMEM, "emit mode 1: cannot allocate the tables (%lld bytes for %lld samples)",
@@ -2608,6 +2616,7 @@ static int tab_setup_sm(ed_batch* b)
   }
   if (ok && hipMemset(b->d_loglik_sm, 0, ((size_t)S * 3 * b->Epad + 512) * 8) != hipSuccess) ok = false;
   if (ok && hipMemcpy(b->d_blk_sm, bm.data(), bm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+  if (ok && ed_null_stream_fence() != hipSuccess) ok = false;
   if (!ok) {     // all of them or none
     void** ptrs[] = {(void**)&b->d_test_sm, (void**)&b->d_ref_sm, (void**)&b->d_blk_sm, (void**)&b->d_vit_queue, (void**)&b->d_loglik_sm};
     for (void** q : ptrs) { if (*q) (void)hipFree(*q); *q = nullptr; }
@@ -2993,6 +3002,7 @@ struct FitWork {
     HIP_TRY(hipMalloc((void**)&n_map, 4));
     HIP_TRY(hipMalloc((void**)&fevals, (size_t)S * 4));
     HIP_TRY(hipMemset(fevals, 0, (size_t)S * 4));
+    HIP_TRY(ed_null_stream_fence());
     HIP_TRY(hipMalloc((void**)&depth, 4));
     HIP_TRY(hipHostMalloc((void**)&h_depth, 4, hipHostMallocDefault));
     *h_depth = -1;

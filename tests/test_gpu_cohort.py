@@ -7,12 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _reference_results(edlib, plan, slabs):
+def _reference_results(edlib, plan, slabs, emit_mode=0):
     """slab by slab, synchronously, through the batch interface"""
     out = []
     for test, ref in slabs:
         n = test.shape[1]
         b = edlib.Batch(plan, n)
+        if emit_mode:
+            b.set_emit_mode(emit_mode)
         dphi = edlib.DeviceArray(np.zeros(n)); dexp = edlib.DeviceArray(np.zeros(n))
         b.fit(test, ref, dphi, dexp)
         b.run(test, ref, dphi, dexp)
@@ -22,9 +24,20 @@ def _reference_results(edlib, plan, slabs):
     return out
 
 
+_CACHE = {}
+
+
 def _same(got, want, keys):
-    for k in keys:
-        assert got[k].tobytes() == want[k].tobytes(), k
+    bad = [k for k in keys if got[k].tobytes() != want[k].tobytes()]
+    detail = []
+    for k in bad:                                                  # (what differs, and by how much: a race shows up as a few low bits or as another slab's values)
+        g, w = np.asarray(got[k]), np.asarray(want[k])
+        if g.dtype.names:
+            detail.append((k, [n for n in g.dtype.names if g[n].tobytes() != w[n].tobytes()], int(sum(np.sum(g[n] != w[n]) for n in g.dtype.names))))
+        elif g.shape == w.shape:
+            d = np.abs(g.astype(np.float64) - w.astype(np.float64))
+            detail.append((k, int(np.sum(g != w)), float(np.nanmax(d))))
+    assert not bad, detail
 
 
 @pytest.fixture(scope="module")
@@ -42,10 +55,31 @@ def cohort_data(edlib):
     plan.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(own_queues=0), dict(split=0.0), dict(split=0.6, viterbi_overlap=1), dict(own_queues=0, split=0.5)])
-@pytest.mark.parametrize("in_flight", [1, 2, 3])
-def test_device_slabs_through_the_cohort_equal_the_batch_interface(cohort_data, opts, in_flight):
+def test_lanes_option_is_validated(cohort_data):
     edlib, plan, slabs, want, S = cohort_data
+    co = edlib.Cohort(plan, S, 4)
+    with pytest.raises(edlib.EdError, match="lanes"):
+        co.set_option("lanes", 3)                                  # not a divisor of the four slabs in flight
+    with pytest.raises(edlib.EdError, match="lanes"):
+        co.set_option("lanes", 5)
+    co.set_option("lanes", 2)
+    co.close()
+
+
+# (in_flight 4 / 6 / 8 without the option: two / three / four LANES of two slots -- independent pipelines inside the object; lanes = 1: the one pipeline
+#  the object was before; lanes = in_flight: one-slot lanes, every slab run to completion on its own stream pair beside the others)
+@pytest.mark.parametrize("opts", [dict(), dict(own_queues=0), dict(split=0.0), dict(split=0.6, viterbi_overlap=1), dict(own_queues=0, split=0.5),
+                                  dict(emit_mode=2), dict(emit_mode=2, lanes=1), dict(lanes=2)])
+@pytest.mark.parametrize("in_flight", [1, 2, 3, 4, 6, 8])
+def test_device_slabs_through_the_cohort_equal_the_batch_interface(cohort_data, opts, in_flight):
+    if opts.get("lanes", 1) > 1 and in_flight % opts["lanes"]:
+        pytest.skip("lanes must divide the slabs in flight")
+    edlib, plan, slabs, want, S = cohort_data
+    if opts.get("emit_mode", 0):                                   # the same mode through the batch interface: the cohort must give its bits
+        key = "want_mode_%d" % opts["emit_mode"]
+        if key not in _CACHE:
+            _CACHE[key] = _reference_results(edlib, plan, slabs, opts["emit_mode"])
+        want = _CACHE[key]
     co = edlib.Cohort(plan, S, in_flight, timing=1, **opts)
     dev = [(edlib.DeviceArray(t), edlib.DeviceArray(r)) for t, r in slabs]
     tickets = []

@@ -63,14 +63,30 @@ for r in keep:
 PY
 rm -f $OUT/wf_kernel_trace.csv $OUT/wf_domain_stats.csv
 python - "$OUT" "$TAG" $EXTRA <<'PY'
-import json, sys, time
+import csv, json, sys, time
 sys.path.insert(0, ".")
 from exomedepth_amd import _build
 line = json.load(open(sys.argv[1] + "/bench_line.json"))
-json.dump({"tag": sys.argv[2], "csrc_sha16": _build.csrc_sha16(), "pmc_steps": 3, "kernel_stats_steps": 6,
+# The emission launches of the pipeline's lanes run SIDE BY SIDE (two lanes at the default four slabs in flight): a launch's own duration is then not
+# the chip's time for it.  From the kernel trace of the timed steps: the union of the launches' intervals per launch (= chip time during which an
+# emission launch is active, per launch) and how many are active on average while any is.
+kernel = line["roofline"]["kernel"]
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(sys.argv[1] + "/ks_kernel_trace.csv")) if ("::" + kernel + "(") in r["Kernel_Name"])
+n_lp = max(1, int(line["roofline"]["launches_per_step"]))
+iv = iv[-int(line["steps"]) * n_lp:]                    # the timed steps' launches (the warm-up and priming runs come first)
+union = 0; cur_s, cur_e = iv[0]
+for s_, e_ in iv[1:]:
+    if s_ > cur_e:
+        union += cur_e - cur_s; cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+union += cur_e - cur_s
+overlap = {"launches": len(iv), "mean_ms_per_launch": sum(e_ - s_ for s_, e_ in iv) / len(iv) / 1e6, "union_ms_per_launch": union / len(iv) / 1e6,
+           "launches_in_flight_while_any": sum(e_ - s_ for s_, e_ in iv) / union, "span_ms_per_launch": (iv[-1][1] - iv[0][0]) / len(iv) / 1e6}
+json.dump({"tag": sys.argv[2], "csrc_sha16": _build.csrc_sha16(), "pmc_steps": 3, "kernel_stats_steps": 6, "emission_overlap": overlap,
            "workload": {"exons": 200000, "samples_per_gpu": 1024, "kernel": line["roofline"]["kernel"],
                         "emission_launches_per_run": line["roofline"]["launches_per_step"],
-                        "bench_flags": "defaults (cohort pipeline of the library, two slabs in flight, fit on) " + " ".join(sys.argv[3:])},
+                        "bench_flags": "defaults (cohort pipeline of the library, %d slabs in flight, fit on) " % line["config"]["batches_in_flight"] + " ".join(sys.argv[3:])},
            "taken": time.strftime("%Y-%m-%d %H:%M:%S"), "bench_args": "--steps 2 --warmup 1 (PMC passes); --steps 5 --warmup 1 (kernel trace)"},
           open(sys.argv[1] + "/meta.json", "w"), indent=1)
 PY
