@@ -565,6 +565,7 @@ def main():
                     "an optional mode, not the headline configuration")
     ap.add_argument("--cov", type=int, default=0, help="> 0: the mean model with that many per-exon covariates (csrc/edcov.inc); "
                     "an optional mode, not the headline configuration")
+    ap.add_argument("--lanes", type=int, default=0, help="cohort option `lanes`: 0 (default) = --batches-in-flight / 2 when that is 4, 6 or 8; 1 = one pipeline (round 4's form)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): two batches in flight (fit of the next batch and the Viterbi tail "
                     "of the previous one run underneath the emissions); 0: steps strictly one after the other")
     ap.add_argument("--viterbi-overlap", type=int, default=0, help="pipelined mode only: 0 (default) = all emissions of a batch as one "
@@ -597,9 +598,10 @@ def main():
     ap.add_argument("--config1-steps", type=int, default=20, help="timed steps of the BASELINE configs[1] leg (200 000 x 64, phi given) run after "
                     "the headline and reported under extra.config1 (0 = skip)")
     ap.add_argument("--verify-columns", type=int, default=4, help="columns of the last slabs checked against the CPU oracle after the timed region (0 = skip)")
-    ap.add_argument("--batches-in-flight", type=int, default=4, help="slabs in flight in the library's cohort pipeline = batch objects used in rotation (>= 2).  "
-                    "4 (default): two LANES of two slots -- independent pipelines inside the cohort object, one lane's emission launch fills the CUs that "
-                    "the other's table build and chains leave idle (3.77 against 4.11 ms per step with 2 = one lane; 6: 3.81-3.96; 8: 4.2)")
+    ap.add_argument("--batches-in-flight", type=int, default=6, help="slabs in flight in the library's cohort pipeline = batch objects used in rotation (>= 2).  "
+                    "6 (default): three LANES of two slots -- independent pipelines inside the cohort object, one lane's emission launch fills the CUs that "
+                    "another's table build and chains leave idle (profiles/r05_ab_lanes.txt, one box: 3.72-3.81 ms per step; 4 = two lanes: 3.79-3.90; "
+                    "2 = one lane, round 4's form: 4.17-4.20; 8: 4.2)")
     ap.add_argument("--workflow-reps", type=int, default=3, help="after the timed region (N = 1): the reference's workflow for one cohort end to end -- "
                     "upload, reference sets, calls -- reported under extra.workflow; 0: skip")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
@@ -726,6 +728,8 @@ def main():
         if bins_cohort:
             args.emit_mode, args.counts_layout = "strict", 0
         opts.update(mode_opts(args))
+        if n_batches in (4, 6, 8) and args.lanes != 1:
+            opts["lanes"] = args.lanes if args.lanes > 1 else n_batches // 2      # independent pipelines inside the cohort object (csrc/edcohort.inc)
         if bins_cohort:
             opts["phi_bins"] = args.phi_bins          # the depth-binned model through the same pipeline (option phi_bins)
             if os.environ.get("ED_BENCH_BINS_PIECES"):
@@ -914,6 +918,12 @@ def main():
         verify = leg(verify_against_oracle, ed, eddist, torch, dev, co if use_cohort else None, batches, last_ticket[0] if use_cohort else None,
                                        n_batches, test, ref, phi, p, phi_fit if not use_cohort else None, p_fit if not use_cohort else None,
                                        bool(args.fit), chrom_off, start, end, args.verify_columns, tables=args.emit_mode != "strict")
+    # The headline's cohort object is done: its streams (a hardware queue each) go back before the other legs make theirs -- with the four slabs / two lanes
+    # of the default line, the 200 000 x 64 leg's six-slot pipeline otherwise finds the device's hardware queues oversubscribed now and then and runs
+    # its slabs one after the other (1.6 ms per slab instead of 0.66, bimodal from run to run).
+    if use_cohort:
+        co.close()
+        co = None
     fit_conc = None
     if world == 1 and args.fit and plain and not args.fused and args.fit_concordance > 0:
         from exomedepth_amd import concordance
@@ -924,7 +934,7 @@ def main():
         config1 = leg(config1_leg, ed, torch, plan, test, ref, phi, p, E, args.config1_steps, mode_opts(args))
     staged = None
     if world == 1 and args.stage_inputs and use_cohort:
-        staged = leg(staged_leg, ed, torch, plan, test, ref, phi, p, E, S, n_batches, args)
+        staged = leg(staged_leg, ed, torch, plan, test, ref, phi, p, E, S, min(n_batches, 2), args)     # (host-fed slabs: two / three slabs in flight, one lane -- the link is the bound)
     workflow = None
     if args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64 and (world == 1 or use_pg):
         workflow = leg(workflow_leg, ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode], world, rank, eddist)
@@ -979,7 +989,7 @@ def main():
                          "frac_with_likelihood_matrix": (33 * E * S / t_emit / 1e9 / HBM_PEAK_GBS) if t_emit > 0 else None,
                          "frac_alone_with_likelihood_matrix": (33 * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "kernel_ms_alone": alone_ms,
-                         "launch_overlap": {"lanes": (n_batches // 2 if (use_cohort and n_batches in (4, 6, 8)) else 1),
+                         "launch_overlap": {"lanes": (opts.get("lanes", 1) if use_cohort else 1),
                                             "from_profile": (meta.get("emission_overlap") if meta else None),
                                             "frac_union": ((ALGO_BYTES_PER_CELL * E * S / n_launch / (meta["emission_overlap"]["union_ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                                            if meta and meta.get("emission_overlap") else None),
@@ -1020,7 +1030,7 @@ def main():
         print(json.dumps(out))
     for b in batches:
         b.close()
-    if use_cohort:
+    if use_cohort and co is not None:
         co.close()
     plan.close()
     if world > 1:

@@ -91,7 +91,7 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             "smplain": ["-DED_SM_NT=0"], "smntld": ["-DED_SM_NT=1"], "smntst": ["-DED_SM_NT=2"],
             "sm512": ["-DED_SM_THREADS=512", "-DED_SM_ENTRIES=3072"],
             # ... 8- and 12-wave workgroups with the whole table window (one per CU, registers left on every SIMD for a Viterbi / table-build wave)
-            "sm512full": ["-DED_SM_THREADS=512"], "sm768full": ["-DED_SM_THREADS=768"],
+            "nofence": ["-DED_X_NO_NULL_FENCE"], "sm512full": ["-DED_SM_THREADS=512"], "sm768full": ["-DED_SM_THREADS=768"],
             "smmask": ["-DED_SM_MASKED=1"], "sm6784": ["-DED_SM_ENTRIES=6784"], "smmask6784": ["-DED_SM_MASKED=1", "-DED_SM_ENTRIES=6784"], "sm4096": ["-DED_SM_ENTRIES=4096"], "sm3584": ["-DED_SM_ENTRIES=3584"], "sm5120": ["-DED_SM_ENTRIES=5120"]}
 
 

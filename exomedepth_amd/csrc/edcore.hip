@@ -77,7 +77,11 @@ static int ed_fail(int code, const char* fmt, ...)
 // started from poisoned partial sums (tests/test_gpu_cohort.py, six slabs in flight, own_queues = 0, torch's HIP runtime in the process: results equal
 // to 1e-15 instead of bit for bit) -- the workspace's all-ones fill landed after the first pass had written its sums.  Every one-time initialisation by
 // hipMemset is therefore followed by this fence before the buffer is handed to a stream.
+#ifdef ED_X_NO_NULL_FENCE      // (diagnostic build only)
+static hipError_t ed_null_stream_fence() { return hipSuccess; }
+#else
 static hipError_t ed_null_stream_fence() { return hipStreamSynchronize(nullptr); }
+#endif
 
 // No C++ exception leaves the library: the callers are C (R's .Call, ctypes).  Every int-returning entry point is a function-try-block
 // closed by ED_CATCH, which turns what was thrown (in practice std::bad_alloc from a host container, std::system_error from a

@@ -468,8 +468,8 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  * host's timing, on GPU_MAX_HW_QUEUES, or on the streams the process used before.  Results are those of ed_batch_fit +
  * ed_batch_run on each slab, bit for bit.
  *   slab_samples     samples per slab (the batch objects are sized for it; a last, smaller slab is accepted)
- *   slabs_in_flight  1: every slab runs to completion before the next (no overlap); 2 or more: pipelined; 4 or 6 (recommended where the
- *                    memory is there -- a slot holds a slab's likelihood matrix, 24 B per cell): two or three LANES of two slots, see "lanes".
+ *   slabs_in_flight  1: every slab runs to completion before the next (no overlap); 2 or more: pipelined; 4 with option "lanes" = 2 is the
+ *                    fastest form for full-width slabs fitted on the device (a slot holds a slab's likelihood matrix, 24 B per cell).
  * Options (ed_cohort_set_option, before the first submission unless noted):
  *   "split"            fraction of a slab's emission launch after which the NEXT slab's fit is issued (default 0.30; 0 = at once)
  *   "own_queues"       1 (default): every stream of the pipeline gets a hardware queue of its own; 0: ordinary streams
@@ -492,8 +492,9 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *   "lanes"            independent pipelines inside the object: slot s belongs to lane s % lanes, a lane has its own emission and fit streams,
  *                      nothing orders the slabs of different lanes against each other (one lane's emission launch fills the CUs that another's
  *                      table build and chains leave idle: 3.70 / 3.63 ms per 200 000 x 1024 slab with 2 / 3 lanes of two slots against 4.04 with
- *                      one).  0 (default): automatic -- slabs_in_flight / 2 lanes when slabs_in_flight is 4, 6 or 8, one lane otherwise; 1..4:
- *                      that many (a divisor of slabs_in_flight).  Results do not depend on it.
+ *                      one).  1 (default): one pipeline; 2..4: that many (a divisor of slabs_in_flight); 0: slabs_in_flight / 2 when that is 4, 6
+ *                      or 8.  Opt-in: it pays for slabs that fill the chip and are fitted on the device, and was measured worse for 64-sample
+ *                      slabs with given parameters and for host-fed (link-bound) slabs.  Results do not depend on it.
  *   "timing"           1: stage times are accumulated (ed_cohort_stage_ms_total); may be switched at any time (resets the sums) */
 typedef struct ed_cohort ed_cohort;
 int ed_cohort_create(ed_cohort** cohort, ed_plan* plan, int64_t slab_samples, int slabs_in_flight);

@@ -66,10 +66,10 @@ def test_lanes_option_is_validated(cohort_data):
     co.close()
 
 
-# (in_flight 4 / 6 / 8 without the option: two / three / four LANES of two slots -- independent pipelines inside the object; lanes = 1: the one pipeline
-#  the object was before; lanes = in_flight: one-slot lanes, every slab run to completion on its own stream pair beside the others)
+# (option lanes: independent pipelines inside the object, slot s in lane s % lanes; 0 = slabs in flight / 2 lanes of two slots when that is 4, 6 or 8;
+#  1, the default: the one pipeline the object was before)
 @pytest.mark.parametrize("opts", [dict(), dict(own_queues=0), dict(split=0.0), dict(split=0.6, viterbi_overlap=1), dict(own_queues=0, split=0.5),
-                                  dict(emit_mode=2), dict(emit_mode=2, lanes=1), dict(lanes=2)])
+                                  dict(lanes=0), dict(lanes=0, own_queues=0), dict(emit_mode=2, lanes=0), dict(emit_mode=2), dict(lanes=2)])
 @pytest.mark.parametrize("in_flight", [1, 2, 3, 4, 6, 8])
 def test_device_slabs_through_the_cohort_equal_the_batch_interface(cohort_data, opts, in_flight):
     if opts.get("lanes", 1) > 1 and in_flight % opts["lanes"]:
