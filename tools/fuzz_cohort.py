@@ -32,14 +32,15 @@ while time.time() - t0 < budget:
         test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, seed, n_segments=2, mean_depth=depth)
         plan = ed.Plan(chrom_off, start, end)
         given = rng.random() < 0.3
-        slab = int(rng.integers(1, S + 1)); nf = int(rng.integers(1, 4))
+        slab = int(rng.integers(1, S + 1)); nf = int(rng.choice([1, 2, 3, 4, 6, 8]))
+        lanes = int(rng.choice([l for l in (1, 1, 2, 3, 4) if nf % l == 0] + ([0] if nf >= 4 else [])))     # (independent pipelines inside the object; 0 = slabs in flight / 2)
         layout = int(rng.integers(0, 2)); wire = int(rng.choice([2, 4]))
         if max(test.max(), ref.max()) >= 65536:
             wire = 4
         dt = np.int32 if wire == 4 else np.uint16
         th = test.astype(dt) if layout == 0 else np.ascontiguousarray(test.T.astype(dt))
         rh = ref.astype(dt) if layout == 0 else np.ascontiguousarray(ref.T.astype(dt))
-        co = ed.Cohort(plan, slab, nf, own_queues=int(rng.integers(0, 2)), split=float(rng.choice([0.0, 0.3, 0.7])))
+        co = ed.Cohort(plan, slab, nf, own_queues=int(rng.integers(0, 2)), split=float(rng.choice([0.0, 0.3, 0.7])), lanes=lanes)
         out = co.run_host(th, rh, layout, phi=phi if given else None, expected=p if given else None, want_path=True)
         path = out["path"] if layout == 0 else out["path"].T
         b = ed.Batch(plan, S)
