@@ -569,6 +569,8 @@ def main():
                     "an optional mode, not the headline configuration")
     ap.add_argument("--cov", type=int, default=0, help="> 0: the mean model with that many per-exon covariates (csrc/edcov.inc); "
                     "an optional mode, not the headline configuration")
+    ap.add_argument("--counts-bits", type=int, default=32, help="16: the headline's device-resident counts are uint16 [samples][exons] (cohort option counts_bits; needs "
+                    "--counts-layout 1): half the bytes of every pass over the counts.  The other legs keep int32")
     ap.add_argument("--lanes", type=int, default=0, help="cohort option `lanes`: 0 (default) = --batches-in-flight / 2 when that is 4, 6 or 8; 1 = one pipeline (round 4's form)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): two batches in flight (fit of the next batch and the Viterbi tail "
                     "of the previous one run underneath the emissions); 0: steps strictly one after the other")
@@ -732,6 +734,8 @@ def main():
         if bins_cohort:
             args.emit_mode, args.counts_layout = "strict", 0
         opts.update(mode_opts(args))
+        if args.counts_bits == 16:
+            opts["counts_bits"] = 16
         if n_batches in (4, 6, 8) and args.lanes != 1:
             opts["lanes"] = args.lanes if args.lanes > 1 else n_batches // 2      # independent pipelines inside the cohort object (csrc/edcohort.inc)
         if bins_cohort:
@@ -744,6 +748,9 @@ def main():
 
         # what the steps are handed: the [E][S] matrices, or (--counts-layout 1) their sample-major images, made once, outside the timed region
         test_in, ref_in = (test.t().contiguous(), ref.t().contiguous()) if args.counts_layout == 1 else (test, ref)
+        if args.counts_bits == 16:
+            assert args.counts_layout == 1 and int(test.max()) < 65536 and int(ref.max()) < 65536 and int(test.min()) >= 0 and int(ref.min()) >= 0
+            test_in, ref_in = test_in.to(torch.int16), ref_in.to(torch.int16)     # (the low 16 bits: uint16 counts in an int16 tensor)
 
         def step():
             step_no[0] += 1
@@ -976,7 +983,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
-                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fit_mode": args.fit_mode, "emit_mode": args.emit_mode, "counts_layout": ("[samples][exons]" if args.counts_layout == 1 else "[exons][samples]"), "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
+                       "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fit_mode": args.fit_mode, "emit_mode": args.emit_mode, "counts_layout": ("[samples][exons]" if args.counts_layout == 1 else "[exons][samples]"), "counts_bits": args.counts_bits, "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
                        "batches_in_flight": n_batches, "driver": ("cohort (ed_cohort_submit: the library's own streams and batch rotation)" if use_cohort else "python (torch streams)"),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered to rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,

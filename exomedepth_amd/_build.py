@@ -70,9 +70,8 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             "knobs": ["-DED_EXPERIMENT_KNOBS"],
             # k_viterbi_sm without its raised wave priority (round 5 A/B: tools/ab.sh vitprio0)
             "vitprio0": ["-DED_VITSM_PRIO=0"], "prepprio3": ["-DED_PREP_PRIO=3"], "prio_prep_over_vit": ["-DED_VITSM_PRIO=0", "-DED_PREP_PRIO=3"], "vitdepth1": ["-DED_VITSM_DEPTH=1"], "fitpre4": ["-DED_FIT_PRE=4"], "tabbuild256": ["-DED_TAB_BUILD_THREADS=256"],
-            # timing experiment (wrong results by construction): k_emit_tab_sm reading its counts as 16-bit elements -- what a 16-bit device-resident
-            # count format would be worth to that kernel (profiles/r05_u16_experiment.txt)
-            "xu16": ["-DED_SM_X_U16"],
+            # (the "xu16" timing build -- k_emit_tab_sm reading its counts as if 16 bits wide, profiles/r05_u16_experiment.txt -- became the real thing:
+            #  ed_batch_set_counts_bits(batch, 16))
             # timing experiments on k_emit_tab_sm (wrong results by construction): without its stores / LDS look-ups / global look-ups
             "xnostore": ["-DED_SM_X_NOSTORE"], "xnolds": ["-DED_SM_X_NOLDS"], "xnoglobal": ["-DED_SM_X_NOGLOBAL"],
             "xnoldsglobal": ["-DED_SM_X_NOLDS", "-DED_SM_X_NOGLOBAL"],

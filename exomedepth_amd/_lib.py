@@ -136,6 +136,7 @@ SYMBOLS = [
     ("ed_batch_set_fit_mode", C.c_int, [_vp, C.c_int]),
     ("ed_batch_set_emit_mode", C.c_int, [_vp, C.c_int]),
     ("ed_batch_set_counts_layout", C.c_int, [_vp, C.c_int]),
+    ("ed_batch_set_counts_bits", C.c_int, [_vp, C.c_int]),
     ("ed_batch_set_emit_tables", C.c_int, [_vp, _i32, _i32, _dbl]),
     ("ed_batch_verify_emissions_tol", C.c_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, C.POINTER(_i64), C.POINTER(_i64),
                                                C.POINTER(_dbl), C.POINTER(_dbl), _vp, _i64]),

@@ -156,10 +156,15 @@ def _device_pointer(x, dtype, keep):
             keep.append(x)
         if not x.is_contiguous():
             raise ValueError("device tensors must be contiguous")
-        want = {np.dtype(np.int32): "torch.int32", np.dtype(np.float64): "torch.float64"}[np.dtype(dtype)]
-        if str(x.dtype) != want:
-            raise ValueError("expected a %s tensor, got %s" % (want, x.dtype))
+        want = {np.dtype(np.int32): ("torch.int32",), np.dtype(np.float64): ("torch.float64",),
+                np.dtype(np.uint16): ("torch.uint16", "torch.int16")}[np.dtype(dtype)]     # (16-bit counts: the bit pattern is what counts)
+        if str(x.dtype) not in want:
+            raise ValueError("expected a %s tensor, got %s" % (want[0], x.dtype))
         return C.c_void_p(x.data_ptr())
+    if np.dtype(dtype) == np.dtype(np.uint16):
+        xa = np.asarray(x)
+        if xa.dtype != np.uint16 and xa.size and (xa.min() < 0 or xa.max() > 65535):
+            raise ValueError("16-bit counts (set_counts_bits(16) / counts_bits = 16) hold 0 .. 65535")
     d = DeviceArray(np.ascontiguousarray(x, dtype=dtype))
     keep.append(d)
     return d.ptr
@@ -271,8 +276,9 @@ class Batch:
         R/class_definition.R:118.  phi_out/expected_out: device float64[n_samples].
         by > 1: fit on exons 0, by, 2*by, ... only (scalar subset.for.speed = n  <=>  by = n_exons // n, :107-113)."""
         keep = []
-        pt = _device_pointer(test, np.int32, keep)
-        pr = _device_pointer(ref, np.int32, keep)
+        cdt = getattr(self, "_cdt", np.int32)
+        pt = _device_pointer(test, cdt, keep)
+        pr = _device_pointer(ref, cdt, keep)
         pp = _device_pointer(phi_out, np.float64, keep)
         pe = _device_pointer(expected_out, np.float64, keep)
         self._keep_fit = keep
@@ -288,8 +294,9 @@ class Batch:
         """Emissions + Viterbi + call table.  Arguments may be torch CUDA tensors (used in place),
         DeviceArrays, or host arrays (uploaded).  Asynchronous on `stream`."""
         keep = []
-        pt = _device_pointer(test, np.int32, keep)
-        pr = _device_pointer(ref, np.int32, keep)
+        cdt = getattr(self, "_cdt", np.int32)
+        pt = _device_pointer(test, cdt, keep)
+        pr = _device_pointer(ref, cdt, keep)
         pp = _device_pointer(phi, np.float64, keep)
         pe = _device_pointer(expected, np.float64, keep)
         self._keep_run = keep  # keep temporaries alive until the next run
@@ -449,11 +456,17 @@ class Batch:
         """0: device count matrices are [n_exons][n_samples]; 1: [n_samples][n_exons] (R's column-major matrix; fit + emit mode 2)"""
         check(lib().ed_batch_set_counts_layout(self.handle, int(layout)))
 
+    def set_counts_bits(self, bits):
+        """32 (default): int32 device counts; 16: uint16, (n_samples, n_exons) -- counts_layout 1 + emit mode 2 only (ed_batch_set_counts_bits)"""
+        check(lib().ed_batch_set_counts_bits(self.handle, int(bits)))
+        self._cdt = np.uint16 if int(bits) == 16 else np.int32
+
     def verify_emissions_tol(self, test, ref, phi, expected, mixture=1.0, rel_tol=1e-10, abs_tol=1e-12, cap=16):
         """verify_emissions with a tolerance: returns a dict(compared, beyond, max_rel, max_abs, first)."""
         keep = []
-        pt = _device_pointer(test, np.int32, keep)
-        pr = _device_pointer(ref, np.int32, keep)
+        cdt = getattr(self, "_cdt", np.int32)
+        pt = _device_pointer(test, cdt, keep)
+        pr = _device_pointer(ref, cdt, keep)
         pp = _device_pointer(phi, np.float64, keep)
         pe = _device_pointer(expected, np.float64, keep)
         first = (_lib.EdEmitMismatch * max(int(cap), 1))()
@@ -573,6 +586,8 @@ class Cohort:
 
     def set_option(self, name, value):
         check(lib().ed_cohort_set_option(self.handle, name.encode(), float(value)))
+        if name == "counts_bits":
+            self._counts_bits = int(value)
         if name == "phi_bins":
             self.phi_bins = int(value)
 
@@ -602,8 +617,9 @@ class Cohort:
         keep = []
         if n_samples is None:
             n_samples = int(test.shape[1])
-        pt = _device_pointer(test, np.int32, keep)
-        pr = _device_pointer(ref, np.int32, keep)
+        cdt = np.uint16 if getattr(self, "_counts_bits", 32) == 16 else np.int32
+        pt = _device_pointer(test, cdt, keep)
+        pr = _device_pointer(ref, cdt, keep)
         pp = _device_pointer(phi, np.float64, keep) if phi is not None else None
         pe = _device_pointer(expected, np.float64, keep) if expected is not None else None
         t = C.c_int64(-1)

@@ -1235,7 +1235,8 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
                             const int32_t* __restrict__ ref, const double* __restrict__ expected, int64_t S,
                             ed_call_info* __restrict__ out, const double* __restrict__ X, int K, const double* __restrict__ beta,
                             int64_t le, int64_t lst, int64_t ls,   // likelihood element (e, st, s) at e * le + st * lst + s * ls
-                            int64_t ce, int64_t cs)                // count of (e, s) at e * ce + s * cs
+                            int64_t ce, int64_t cs,                // count of (e, s) at e * ce + s * cs
+                            int cb)                                // bytes per count: 4, or 2 (ed_batch_set_counts_bits(batch, 16))
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ncalls) return;
@@ -1246,8 +1247,8 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
   double bh = 0, bl = 0, eh = 0, el = 0;
   int64_t obs = 0;
   for (int64_t e = c.start_exon; e <= c.end_exon; ++e) {
-    const int32_t t = test[e * ce + s * cs];
-    const int32_t tot = t + ref[e * ce + s * cs];
+    const int32_t t = ed_ldc(test, e * ce + s * cs, cb);
+    const int32_t tot = t + ed_ldc(ref, e * ce + s * cs, cb);
     double lc, ln;
     if (loglik) {
       lc = loglik[e * le + col * lst + s * ls];
@@ -1346,19 +1347,18 @@ k_fit_moments(const int32_t* __restrict__ test, int64_t trs, int64_t tcs, const 
 __global__ void __launch_bounds__(256)
 k_fit_moments_sm(const int32_t* __restrict__ test, const int32_t* __restrict__ ref, int64_t pitch, int64_t by, int64_t E, int64_t S,
                  int stride, double* __restrict__ partial, double* __restrict__ eta, double* __restrict__ lam, int* __restrict__ done,
-                 int* __restrict__ depth_max)
+                 int* __restrict__ depth_max, int cb)
 {
   __shared__ double red[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t s = blockIdx.x;
-  const int32_t* __restrict__ trow = test + s * pitch;
-  const int32_t* __restrict__ rrow = ref + s * pitch;
+  const int64_t row0 = s * pitch;
   double sy = 0, sn = 0, syy = 0, cnt = 0;
   for (int64_t q = (int64_t)wave * stride; q * 64 < E; q += 4 * (int64_t)stride) {
     const int64_t e = q * 64 + lane;
     if (e < E) {
-      const int y = trow[e * by];
-      const int n = y + rrow[e * by];
+      const int y = ed_ldc(test, row0 + e * by, cb);
+      const int n = y + ed_ldc(ref, row0 + e * by, cb);
       if (n > 0) {
         sy += (double)y; sn += (double)n;
         syy += ((double)y * (double)y) / (double)n;
@@ -1828,6 +1828,9 @@ struct ed_batch {
   hipStream_t fin = nullptr;
   hipEvent_t done_ev = nullptr, fork_ev = nullptr;
   int last_layout = 0;                  // counts_layout of the last run's inputs
+  int counts_bits = 32;                 // 32: int32 counts; 16: uint16 (sample-major table mode only: ed_batch_set_counts_bits)
+  int last_cb = 4;                      // bytes per count of the last run's inputs
+  int cb() const { return counts_bits == 16 ? 2 : 4; }
   const int32_t* last_test = nullptr;   // inputs of the last ed_batch_run (for ed_batch_copy_call_info)
   const int32_t* last_ref = nullptr;
   const double* last_expected = nullptr;
@@ -2655,7 +2658,7 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
   const int64_t E = b->plan->E, S = b->S;
   const int step = E >= 4096 ? 16 : 1;     // (d_tacc, d_notab[0], d_cold_n were zeroed by k_sample_consts, launched right before this on the same stream)
   if (E > 0 && b->counts_layout == 1)
-    hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S, 4), dim3(64), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc);
+    hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S, 4), dim3(64), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc, b->cb());
   else if (E > 0)
     hipLaunchKernelGGL(k_tab_stats, dim3((unsigned)((S + 63) / 64), (unsigned)((E + 64 * step - 1) / (64 * step))), dim3(256), 0, st, d_test, d_ref, E, S,
                        step, b->d_tacc);
@@ -2714,6 +2717,8 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   b->rows_valid = !tabsm;
   const bool cl1 = b->counts_layout == 1;                       // counts handed over sample-major [S][E]
   if (cl1 && !tabsm) return ed_fail(ED_ERR_STATE, "ed_batch_run: sample-major counts (ed_batch_set_counts_layout(batch, 1)) are served by emit mode 2 only");
+  if (b->counts_bits == 16 && !(cl1 && tabsm)) return ed_fail(ED_ERR_STATE, "ed_batch_run: 16-bit counts (ed_batch_set_counts_bits(batch, 16)) are served by counts_layout 1 + emit mode 2 only");
+  const int cb = b->cb();
   HIP_TRY(hipSetDevice(b->plan->device));   // the caller's thread may have another device current (one process, many GPUs)
   hipStream_t st = (hipStream_t)stream_;
   const ed_plan* p = b->plan;
@@ -2726,7 +2731,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
   if (b->ran && b->last_run_async && b->done_ev) HIP_TRY(hipStreamWaitEvent(st, b->done_ev, 0));
   b->stream = tail;
   b->split_recorded = false;
-  b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected; b->last_layout = b->counts_layout;
+  b->last_test = d_test; b->last_ref = d_ref; b->last_expected = d_expected; b->last_layout = b->counts_layout; b->last_cb = cb;
   struct SrcClear { ed_batch* b; ~SrcClear() { b->src_phi = b->src_exp = nullptr; } } src_clear{b};   // (whatever path the run takes)
   b->last_cov_X = em.cov ? em.X : nullptr; b->last_cov_K = em.cov ? em.K : -1; b->last_cov_beta = em.cov ? em.beta : nullptr;
   const bool ready = plain && b->prepared && b->prepared_phi == d_phi && b->prepared_exp == d_expected && b->prepared_mix == mixture && !b->fused;
@@ -2768,7 +2773,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(nsplit, n / 32));
       const int64_t nwg = ((S + 7) / 8) * 8 * nsplit;
       hipLaunchKernelGGL(k_emit_tab_sm, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
-                         b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap);
+                         b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, cl1 ? cb : 4);
       return;
     }
     const uint32_t nsb = (uint32_t)((S + b->tab_tw - 1) / b->tab_tw);
@@ -2878,7 +2883,7 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
         hipLaunchKernelGGL(k_tab_cold, dim3(1024), dim3(256), 0, st, csm ? (cl1 ? d_test : b->d_test_sm) : d_test, csm ? (cl1 ? d_ref : b->d_ref_sm) : d_ref,
                            b->d_consts, b->d_cflags, b->d_tdims, b->d_cold_list, b->d_cold_n,
                            b->cold_cap, b->d_seg_t, j0, j1, S, tabsm ? b->d_loglik_sm : b->d_loglik, b->d_nerr, tabsm ? (int64_t)1 : 3 * S,
-                           tabsm ? b->Epad : S, tabsm ? 3 * b->Epad : (int64_t)1, csm ? (int64_t)1 : S, csm ? E : (int64_t)1, b->d_notab, b->d_nerr + 2);
+                           tabsm ? b->Epad : S, tabsm ? 3 * b->Epad : (int64_t)1, csm ? (int64_t)1 : S, csm ? E : (int64_t)1, b->d_notab, b->d_nerr + 2, cl1 ? cb : 4);
       }
       else if (plain && nblk > 0)   // the out-of-domain tasks of this group, if k_emit_batch met any (returns at once otherwise)
         hipLaunchKernelGGL(k_emit_cold, dim3(512), dim3(256), 0, st, d_test, d_ref, b->d_consts, b->d_seg, j0, j1, S, b->d_loglik,
@@ -3041,11 +3046,12 @@ constexpr int kFitCoarsePasses = ED_FIT_COARSE;   // Newton steps on every 16th 
 // out like the reference counts: tcs == 1, trs == rrs); otherwise per-cell passes, one launch pair per pass.
 static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t tcs, const int32_t* d_ref, int64_t rrs,
                        int64_t E, int64_t S, double* d_phi, double* d_expected, hipStream_t st, int use_hist = 0, int fit_mode = 0,
-                       int64_t tmod = 0, int skip_K = 0, int* d_skip_from = nullptr, int64_t sm_pitch = 0)
+                       int64_t tmod = 0, int skip_K = 0, int* d_skip_from = nullptr, int64_t sm_pitch = 0, int cb = 4)
 {
   // sm_pitch > 0: SAMPLE-MAJOR counts -- column s is the row test[s * sm_pitch + e * trs] (trs = the exon step, 1 or subset.for.speed's);
   // histogram form only
   const bool sm = sm_pitch > 0;
+  if (cb != 4 && !sm) return ed_fail(ED_ERR_STATE, "fit: 16-bit counts (ed_batch_set_counts_bits(batch, 16)) are fitted from sample-major matrices only (counts_layout 1)");
   if (sm && (!use_hist || tmod)) return ed_fail(ED_ERR_STATE, "fit: sample-major counts are fitted on the count histograms only (ed_batch_set_fit_histograms(batch, 0) excludes them)");
   const int64_t nblk = (E + kFitChunk - 1) / kFitChunk;
   const int64_t nch = sm ? 1 : nblk * kFitSub;   // chunks THIS fit writes (the workspace may have been sized for more exons)
@@ -3056,7 +3062,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   // (fit mode 1 starts from aod's glm-binomial intercept logit(sum y / sum n) over ALL exons; the Newton fit only needs a rough start)
   HIP_TRY(hipMemsetAsync(w.depth, 0, 4, st));
   if (sm) hipLaunchKernelGGL(k_fit_moments_sm, dim3((unsigned)S), dim3(256), 0, st, d_test, d_ref, sm_pitch, trs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial,
-                             w.eta, w.lam, w.done, w.depth);
+                             w.eta, w.lam, w.done, w.depth, cb);
   else {
     hipLaunchKernelGGL(k_fit_moments, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, fit_mode == 1 ? 1 : (E >= 65536 ? 16 : 4), w.partial, tmod);
     hipLaunchKernelGGL(k_fit_start, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, w.depth);
@@ -3075,7 +3081,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
 #define ED_FIT_HIST(NS, CAP)                                                                                                       \
     if ((launched & fit_hist_bit(NS::kHistId)) && sm)                                                                          \
       hipLaunchKernelGGL(NS::k_fit_hist_sm, dim3((unsigned)S), dim3(NS::kHsBlock), 0, st, d_test, d_ref, sm_pitch, trs, E, S, w.hist, w.ov_y, w.ov_r, \
-                         w.ovn, CAP, w.depth, launched);                                                                        \
+                         w.ovn, CAP, w.depth, launched, cb);                                                                      \
     else if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hist, dim3((unsigned)((((S + NS::kHistSamples - 1) / NS::kHistSamples * NS::kHistHalves + 7) / 8) * 8)), \
                          dim3(NS::kHistBlock), 0, st, d_test, d_ref, rrs, E, S, w.hist, w.ov_y, w.ov_r, w.ovn, CAP, w.depth, launched);
@@ -3085,7 +3091,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnm, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y,     \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 2000 /* optim(control = list(maxit = 2000)) */, d_test, d_ref, cell_rs,  \
-                         E, w.depth, launched, w.fevals, cell_cs, d_phi, d_expected, sm ? 1 : 0);
+                         E, w.depth, launched, w.fevals, cell_cs, d_phi, d_expected, sm ? 1 : 0, cb);
     if (fit_mode == 1) {
       ED_FIT_NM(hg8, w.cap8) ED_FIT_NM(hg4, w.cap4) ED_FIT_NM(hg2, w.cap2)
       HIP_TRY(hipGetLastError());
@@ -3096,7 +3102,7 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (launched & fit_hist_bit(NS::kHistId))                                                                                 \
       hipLaunchKernelGGL(NS::k_fit_hnewton, dim3((unsigned)((S + NS::kHnS - 1) / NS::kHnS)), dim3(NS::kHnS, NS::kHnY), 0, st, w.hist, w.ov_y, \
                          w.ov_r, w.ovn, CAP, S, w.eta, w.lam, w.done, 100, 1e-9 /* iterations are cheap here: converge tightly */, \
-                         d_test, d_ref, cell_rs, E, w.depth, launched, cell_cs, d_phi, d_expected, sm ? 1 : 0);
+                         d_test, d_ref, cell_rs, E, w.depth, launched, cell_cs, d_phi, d_expected, sm ? 1 : 0, cb);
     ED_FIT_NEWTON(hg8, w.cap8) ED_FIT_NEWTON(hg4, w.cap4) ED_FIT_NEWTON(hg2, w.cap2)
 #undef ED_FIT_NEWTON
     HIP_TRY(hipGetLastError());
@@ -3151,9 +3157,11 @@ try {
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[5], st));
   const int64_t rows = (E - 1) / by + 1;
   if (b->counts_layout == 1) {
-    if (int rc = fit_columns(*b->fitw, d_test, by, 1, d_ref, by, rows, S, d_phi, d_expected, st, b->fit_hist, b->fit_mode, 0, 0, nullptr, E)) return rc;
-  } else
-  if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist, b->fit_mode)) return rc;
+    if (int rc = fit_columns(*b->fitw, d_test, by, 1, d_ref, by, rows, S, d_phi, d_expected, st, b->fit_hist, b->fit_mode, 0, 0, nullptr, E, b->cb())) return rc;
+  } else {
+    if (b->counts_bits == 16) return ed_fail(ED_ERR_STATE, "ed_batch_fit: 16-bit counts (ed_batch_set_counts_bits(batch, 16)) come sample-major (ed_batch_set_counts_layout(batch, 1))");
+    if (int rc = fit_columns(*b->fitw, d_test, S * by, 1, d_ref, S * by, rows, S, d_phi, d_expected, st, b->fit_hist, b->fit_mode)) return rc;
+  }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[6], st));
   b->have_fit_time = b->timing;
   return ED_OK;
@@ -3247,6 +3255,18 @@ try {
   return ED_OK;
 }
 ED_CATCH("ed_batch_set_counts_layout")
+
+// 16: the count matrices handed to ed_batch_fit / ed_batch_run are uint16 [n_samples][n_exons] (counts below 65 536) -- half the bytes of every pass over them.
+// Served by the sample-major table mode only (counts_layout 1, emit mode 2, per-sample dispersion); anything else says so when it is run.
+ED_EXPORT int ed_batch_set_counts_bits(ed_batch* b, int bits)
+try {
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  if (bits != 32 && bits != 16) return ed_fail(ED_ERR_INVALID, "ed_batch_set_counts_bits: 32 (int32) or 16 (uint16)");
+  b->counts_bits = bits;
+  b->prepared = false;
+  return ED_OK;
+}
+ED_CATCH("ed_batch_set_counts_bits")
 
 ED_EXPORT int ed_batch_set_emit_tables(ed_batch* b, int32_t cap_obs, int32_t cap_ref, double reach)
 try {
@@ -3363,7 +3383,7 @@ try {
                      (b->keep_loglik || !b->fused) ? (b->rows_valid ? b->d_loglik : b->d_loglik_sm) : (double*)nullptr, b->d_consts, b->last_test, b->last_ref,
                      b->last_expected, b->S, b->d_info, b->last_cov_X, b->last_cov_K, b->last_cov_beta, b->rows_valid ? 3 * b->S : (int64_t)1,
                      b->rows_valid ? b->S : b->Epad, b->rows_valid ? (int64_t)1 : 3 * b->Epad, b->last_layout ? (int64_t)1 : b->S,
-                     b->last_layout ? b->plan->E : (int64_t)1);
+                     b->last_layout ? b->plan->E : (int64_t)1, b->last_cb);
   HIP_TRY(hipGetLastError());
   if (int rc = ed_d2h(host_info, b->d_info, (size_t)k * sizeof(ed_call_info), b->stream)) return rc;
   return ED_OK;
@@ -3395,6 +3415,7 @@ ED_EXPORT int ed_batch_verify_emissions(ed_batch* b, const int32_t* d_test, cons
                                         const double* d_expected, double mixture, int64_t* n_compared, int64_t* n_mismatch,
                                         ed_emit_mismatch* first, int64_t cap)
 try {
+  if (b && b->counts_bits == 16) return ed_fail(ED_ERR_STATE, "ed_batch_verify_emissions: 16-bit counts are checked by ed_batch_verify_emissions_tol");
   if (int rc = batch_ready(b)) return rc;
   if (!d_test || !d_ref || !d_phi || !d_expected || !n_compared || !n_mismatch || cap < 0 || (cap > 0 && !first))
     return ed_fail(ED_ERR_INVALID, "ed_batch_verify_emissions: bad arguments");
@@ -3446,7 +3467,7 @@ try {
   const int64_t eblk = (E + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL(k_emit_verify_tol, dim3((unsigned)((S + 63) / 64), (unsigned)std::min<int64_t>(eblk, 65535), (unsigned)((eblk + 65534) / 65535)),
                      dim3(kEmitBlock), 0, b->stream, d_test, d_ref, d_phi, d_expected, mixture, E, S, b->d_loglik, rel_tol, abs_tol,
-                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap, b->counts_layout ? (int64_t)1 : S, b->counts_layout ? E : (int64_t)1);
+                     dcnt.as<unsigned long long>(), dfirst.as<ed_emit_mismatch>(), cap, b->counts_layout ? (int64_t)1 : S, b->counts_layout ? E : (int64_t)1, b->counts_layout ? b->cb() : 4);
   HIP_TRY(hipGetLastError());
   unsigned long long c[5] = {0, 0, 0, 0, 0};
   if (int rc = ed_d2h(c, dcnt.p, 40, b->stream)) return rc;

@@ -308,6 +308,11 @@ int ed_batch_set_emit_mode(ed_batch* batch, int mode);
  * served by the histogram fit and by emit mode 2 (which works sample-major throughout: with layout 0 it first transposes the
  * counts); the depth-binned and covariate models take layout 0. */
 int ed_batch_set_counts_layout(ed_batch* batch, int layout);
+/* Width of the DEVICE counts: 32 (default) int32 -- R's integers; 16: uint16 [n_samples][n_exons] (counts below 65 536; the pointers are passed as
+ * const int32_t* all the same) -- half the bytes of every pass over the counts (moments, histograms, table statistics, emissions, strict pass,
+ * decoration).  Served by counts_layout 1 + emit mode 2 + the per-sample dispersion model only; anything else returns ED_ERR_STATE when it is run.
+ * Same results as the int32 form (the fit to its tolerance: a sample's overflow cells are met in another order). */
+int ed_batch_set_counts_bits(ed_batch* batch, int bits);
 int ed_batch_set_emit_tables(ed_batch* batch, int32_t cap_obs, int32_t cap_ref, double reach);
 /* Tolerance form of ed_batch_verify_emissions: |matrix - per-cell evaluation| <= max(abs_tol, rel_tol |per-cell value|) (NaN matches
  * NaN).  n_beyond counts values outside it; max_rel / max_abs (optional) the largest differences seen among finite values. */
@@ -486,6 +491,8 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *   "emit_mode"        0 (default) strict, 1 tables, 2 tables sample-major: ed_batch_set_emit_mode for every slab (phi_bins must be 1)
  *   "counts_layout"    0 (default): device counts [n_exons][n_samples]; 1: [n_samples][n_exons] (needs emit_mode 2): ed_cohort_submit takes
  *                      them that way, and host-fed slabs in layout 1 (R's column-major matrix) are uploaded without a transposition
+ *   "counts_bits"      32 (default) / 16: ed_batch_set_counts_bits for every slab -- device-resident uint16 counts (needs counts_layout 1 and
+ *                      emit_mode 2; host-fed slabs are widened to int32 on the device and do not take it)
  *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
  *   "tables_early"     1: a slab's per-sample constants and tables are made right behind its fit, on the fit stream; 0 (default):
  *                      between two emission launches (the same work either way: measured equal)

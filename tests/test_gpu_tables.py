@@ -432,6 +432,75 @@ def test_sample_major_counts(edlib):
     plan.close()
 
 
+@pytest.mark.parametrize("E,depth", [(5000, 110.0), (4096 * 3 + 17, 25.0), (70000, 400.0)])
+def test_sixteen_bit_counts(edlib, E, depth):
+    """ed_batch_set_counts_bits(16): uint16 [n_samples][n_exons] device counts through the sample-major table mode -- moments, histograms (16-byte loads of
+    eight counts, spans of 2 048 exons, the scalar remainder), table statistics, emissions, the strict pass for cells outside the tables, the decoration: the
+    same likelihood bits, paths, calls and decoration as the int32 form given the same parameters; the same fit to its tolerance (a sample's overflow cells
+    are met in another order); through the cohort pipeline too.  Counts that do not fit, other modes and host-fed slabs say so."""
+    S = 96
+    chrom_off, start, end = synth.exon_design(E, 5, 21)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 21, n_segments=4, mean_depth=depth)
+    test[5, 3] = 0; ref[5, 3] = 0
+    test[11, :] = test[11, :] * 40                                     # cells beyond the tables (the strict list)
+    test, ref = np.minimum(test, 65535), np.minimum(ref, 65535)        # (what the format holds)
+    tt, rt = np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)
+    t16, r16 = tt.astype(np.uint16), rt.astype(np.uint16)
+    assert np.array_equal(t16.astype(np.int32), tt) and np.array_equal(r16.astype(np.int32), rt)
+    plan = ed.Plan(chrom_off, start, end)
+    a = ed.Batch(plan, S); a.set_emit_mode(2); a.set_counts_layout(1)
+    b = ed.Batch(plan, S); b.set_emit_mode(2); b.set_counts_layout(1); b.set_counts_bits(16)
+    fa = [ed.DeviceArray(np.zeros(S)) for _ in range(2)]
+    fb = [ed.DeviceArray(np.zeros(S)) for _ in range(2)]
+    a.fit(tt, rt, fa[0], fa[1]); b.fit(t16, r16, fb[0], fb[1])
+    for x, y in zip(fa, fb):
+        x, y = x.to_host(), y.to_host()
+        assert np.all(np.abs(x - y) <= 1e-9 * np.abs(x)), np.max(np.abs(x - y) / np.abs(x))
+    assert a.fit_unconverged()[0] == b.fit_unconverged()[0] == 0
+    a.run(tt, rt, phi, p); b.run(t16, r16, phi, p)
+    assert np.array_equal(bits(a.loglik()), bits(b.loglik()))
+    assert np.array_equal(a.path(), b.path()) and np.array_equal(a.calls(), b.calls()) and len(a.calls()) > 0
+    assert np.array_equal(a.call_info(), b.call_info())
+    assert a.n_gsl_errors() == b.n_gsl_errors() and a.table_stats() == b.table_stats() and a.table_stats()["n_cold_cells"] > 0
+    v = b.verify_emissions_tol(t16, r16, phi, p, rel_tol=REL_TOL, abs_tol=ABS_TOL)          # the device-side check reads the 16-bit counts too
+    assert v["compared"] == E * S * 3 and v["beyond"] == 0, v
+    # fitted on the device and run with what was fitted: the same calls (the parameters agree to 1e-9)
+    a.run(tt, rt, fa[0], fa[1]); b.run(t16, r16, fb[0], fb[1])
+    assert np.array_equal(a.path(), b.path()) and np.array_equal(a.calls(), b.calls())
+    # strided fit and fit mode 1
+    a.fit(tt, rt, fa[0], fa[1], by=7); b.fit(t16, r16, fb[0], fb[1], by=7)
+    assert np.all(np.abs(fa[0].to_host() - fb[0].to_host()) <= 1e-8 * fa[0].to_host())
+    from exomedepth_amd._lib import check, lib
+    for m in (a, b):
+        check(lib().ed_batch_set_fit_mode(m.handle, 1))
+    a.fit(tt, rt, fa[0], fa[1]); b.fit(t16, r16, fb[0], fb[1])
+    assert np.all(np.abs(fa[0].to_host() - fb[0].to_host()) <= 5e-3 * fa[0].to_host())
+    # through the cohort pipeline (device slabs)
+    want_calls, want_path = None, None
+    for bits_ in (32, 16):
+        co = ed.Cohort(plan, S, 2, emit_mode=2, counts_layout=1, counts_bits=bits_)
+        tk = co.submit(ed.DeviceArray(tt if bits_ == 32 else t16), ed.DeviceArray(rt if bits_ == 32 else r16), n_samples=S)
+        got = co.results(tk, S, path=True)
+        if want_calls is None:
+            want_calls, want_path = got["calls"], got["path"]
+        else:
+            assert np.array_equal(got["calls"], want_calls) and np.array_equal(got["path"], want_path)
+            with pytest.raises(Exception, match="counts_bits"):
+                co.submit_host(t16, r16, 1)
+        co.close()
+    # what does not take the format says so
+    with pytest.raises(ValueError, match="65535"):
+        b.run(tt + 70000, rt, phi, p)
+    c = ed.Batch(plan, S); c.set_emit_mode(2); c.set_counts_bits(16)
+    with pytest.raises(Exception, match="counts_layout 1"):
+        c.run(t16, r16, phi, p)
+    with pytest.raises(Exception, match="sample-major"):
+        c.fit(t16, r16, fb[0], fb[1])
+    for m in (a, b, c):
+        m.close()
+    plan.close()
+
+
 def test_cohort_pipeline_in_table_modes(edlib):
     """slabs through the cohort pipeline (two in flight) in emit modes 1 and 2, device counts in both layouts and host-fed slabs in R's
     layout: the calls of the strict pipeline, the fitted parameters to the fit's tolerance"""
