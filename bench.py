@@ -261,13 +261,18 @@ def mode_opts(args):
     return o
 
 
-def mode_leg(ed, torch, plan, test, ref, S, steps, fit, phi, p, opts):
-    """the headline's steps once more under other cohort options (another emission mode, the other count layout): ms per step"""
-    co = ed.Cohort(plan, S, 2, **opts)
+def mode_leg(ed, torch, plan, test, ref, S, steps, fit, phi, p, opts, in_flight=2):
+    """the headline's steps once more under other cohort options (another emission mode, the other count layout, 16-bit counts): ms per step"""
+    co = ed.Cohort(plan, S, in_flight, **opts)
     if opts.get("counts_layout") == 1:
         test, ref = test.t().contiguous(), ref.t().contiguous()
+    if opts.get("counts_bits") == 16:
+        if int(test.max()) >= 65536 or int(ref.max()) >= 65536:
+            co.close()
+            return None
+        test, ref = test.to(torch.int16), ref.to(torch.int16)       # (the low 16 bits: uint16 counts in an int16 tensor)
     sub = (lambda: co.submit(test, ref, n_samples=S)) if fit else (lambda: co.submit(test, ref, phi=phi, expected=p, n_samples=S))
-    for _ in range(3):
+    for _ in range(in_flight + 1):
         sub()
     co.drain()
     torch.cuda.synchronize()
@@ -743,6 +748,7 @@ def main():
             if os.environ.get("ED_BENCH_BINS_PIECES"):
                 opts["bins_pieces"] = int(os.environ["ED_BENCH_BINS_PIECES"])
         co = ed.Cohort(plan, S, n_batches, **opts)
+        opts_headline = dict(opts)
         batches = []
         last_ticket = [-1]
 
@@ -955,10 +961,16 @@ def main():
                        "fit_mode_1": (leg(mode_leg, ed, torch, plan, test, ref, S, args.strict_steps, True, phi, p, {**mode_opts(args), "fit_mode": 1})
                                       if args.fit and args.fit_mode == 0 else None),
                        "tables_counts_exons_x_samples": leg(mode_leg, ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {"emit_mode": 2}),
+                       "tables_counts_16_bit": (leg(mode_leg, ed, torch, plan, test, ref, S, 2 * args.strict_steps, args.fit, phi, p,
+                                                    {**opts_headline, "counts_bits": 16, "timing": 0}, n_batches) if args.counts_layout == 1 and args.counts_bits == 32 else None),
+                       "tables_counts_32_bit_same_leg": (leg(mode_leg, ed, torch, plan, test, ref, S, 2 * args.strict_steps, args.fit, phi, p,
+                                                             {**opts_headline, "timing": 0}, n_batches) if args.counts_layout == 1 and args.counts_bits == 32 else None),
                        "note": "the same workload and pipeline, after the timed region: strict = emit mode 0 (GSL's arithmetic operation for operation, "
                                "bit-identical to the checker: rounds 1-3's headline); fit_mode_1 = the headline's mode with the dispersion fit by "
                                "aod::betabin's Nelder-Mead procedure (--fit-mode 1) instead of Newton's method; tables_counts_exons_x_samples = the headline's mode handed "
-                               "[exons][samples] count matrices (it then transposes them inside every step)"}
+                               "[exons][samples] count matrices (it then transposes them inside every step); tables_counts_16_bit = the headline's mode, slabs in flight and lanes with the "
+                               "device-resident counts as uint16 (cohort option counts_bits = 16: half the bytes of every pass over the counts; same likelihood bits, paths, calls), and "
+                               "tables_counts_32_bit_same_leg = the headline's own configuration run the same way right after it, for comparison"}
 
     if rank == 0:
         kernel = "k_emit_viterbi" if args.fused else ({"strict": "k_emit_batch", "tables-tile": "k_emit_tab", "tables": "k_emit_tab_sm"}[args.emit_mode] if plain else "k_emit_bins")

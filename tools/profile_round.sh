@@ -71,7 +71,9 @@ line = json.load(open(sys.argv[1] + "/bench_line.json"))
 # the chip's time for it.  From the kernel trace of the timed steps: the union of the launches' intervals per launch (= chip time during which an
 # emission launch is active, per launch) and how many are active on average while any is.
 kernel = line["roofline"]["kernel"]
-iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(sys.argv[1] + "/ks_kernel_trace.csv")) if ("::" + kernel + "(") in r["Kernel_Name"])
+import re
+pat = re.compile(r"::" + re.escape(kernel) + r"(<[^>]*>)?\(")          # (a template kernel's name carries its arguments)
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(sys.argv[1] + "/ks_kernel_trace.csv")) if pat.search(r["Kernel_Name"]))
 n_lp = max(1, int(line["roofline"]["launches_per_step"]))
 iv = iv[-int(line["steps"]) * n_lp:]                    # the timed steps' launches (the warm-up and priming runs come first)
 union = 0; cur_s, cur_e = iv[0]
