@@ -32,7 +32,7 @@ def close_floor(got, want):
 
 
 t0 = time.time()
-n_cases = n_cells = n_disc_states = n_disc_calls = n_oracle_cols = n_cold = n_notab = n_samples = n_floor = 0
+n_cases = n_cells = n_disc_states = n_disc_calls = n_oracle_cols = n_cold = n_notab = n_samples = n_floor = n_u16 = 0
 worst_a12 = 0.0
 worst = 0.0
 worst_at = None
@@ -91,6 +91,10 @@ while time.time() - t0 < budget:
         b.set_emit_mode(mode, **caps)
         b.set_counts_layout(layout)
         t_in, r_in = (np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)) if layout else (test, ref)
+        if layout == 1 and rng.random() < 0.5 and test.min() >= 0 and ref.min() >= 0 and max(test.max(), ref.max()) < 65536:
+            b.set_counts_bits(16)                   # the 16-bit device format: the same bits as int32
+            t_in, r_in = t_in.astype(np.uint16), r_in.astype(np.uint16)
+            n_u16 += 1
         for _ in range(int(rng.integers(1, 3))):
             b.run(t_in, r_in, phi, p, mixture=mixture)
         ll, path, calls = b.loglik(), b.path(), b.calls()
@@ -141,6 +145,6 @@ while time.time() - t0 < budget:
     n_cases += 1
 print("fuzz_tables ok: %d cases, %d cells in table modes, max relative difference from strict mode %.2e (bar 1e-10, no absolute floor; %d values would have "
       "needed the 1e-12 floor), %d discordant Viterbi states, %d discordant call rows, %d columns against the checker's libm flavour, "
-      "%d cells on the strict lists, %d of %d samples without tables, %.0f s"
-      % (n_cases, n_cells, worst, n_floor, n_disc_states, n_disc_calls, n_oracle_cols, n_cold, n_notab, n_samples, time.time() - t0))
+      "%d cells on the strict lists, %d of %d samples without tables, %d runs on 16-bit counts, %.0f s"
+      % (n_cases, n_cells, worst, n_floor, n_disc_states, n_disc_calls, n_oracle_cols, n_cold, n_notab, n_samples, n_u16, time.time() - t0))
 print("  the largest difference:", worst_at)
