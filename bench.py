@@ -577,7 +577,7 @@ def main():
     ap.add_argument("--counts-bits", type=int, default=32, help="16: the headline's device-resident counts are uint16 [samples][exons] (cohort option counts_bits; needs "
                     "--counts-layout 1): half the bytes of every pass over the counts.  The other legs keep int32")
     ap.add_argument("--lanes", type=int, default=0, help="cohort option `lanes`: 0 (default) = --batches-in-flight / 2 when that is 4, 6 or 8; 1 = one pipeline (round 4's form)")
-    ap.add_argument("--pipeline", type=int, default=1, help="1 (default): two batches in flight (fit of the next batch and the Viterbi tail "
+    ap.add_argument("--pipeline", type=int, default=1, help="1 (default): --batches-in-flight slabs in flight (fit of the next batch and the Viterbi tail "
                     "of the previous one run underneath the emissions); 0: steps strictly one after the other")
     ap.add_argument("--viterbi-overlap", type=int, default=0, help="pipelined mode only: 0 (default) = all emissions of a batch as one "
                     "launch, its chains afterwards, next to the next batch's fit; 1 = chains of a chromosome group underneath "
