@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--emit-mode", default="tables", choices=["strict", "tables", "tables-tile"])
     ap.add_argument("--fit", type=int, default=1, help="1: (phi, expected) fitted on the device (BASELINE configs[2]); 0: the generator's (configs[1])")
     ap.add_argument("--deep", action="store_true")
+    ap.add_argument("--counts-bits", type=int, default=32, help="16: the device counts as uint16 (ed_batch_set_counts_bits; tables mode)")
     ap.add_argument("--seed", type=int, default=20250621)
     ap.add_argument("--threads", type=int, default=0)
     args = ap.parse_args()
@@ -54,6 +55,10 @@ def main():
         b.set_emit_mode(mode)
     b.set_counts_layout(layout)
     t_in, r_in = (np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)) if layout else (test, ref)
+    if args.counts_bits == 16:
+        assert layout == 1 and test.min() >= 0 and ref.min() >= 0 and max(test.max(), ref.max()) < 65536
+        b.set_counts_bits(16)
+        t_in, r_in = t_in.astype(np.uint16), r_in.astype(np.uint16)
     dt, dr = ed.DeviceArray(t_in), ed.DeviceArray(r_in)
     if args.fit or args.deep:
         dphi, dexp = ed.DeviceArray(np.zeros(S)), ed.DeviceArray(np.zeros(S))
@@ -98,7 +103,7 @@ def main():
     out = {"workload": "%d exons x %d samples, 24 chromosomes, %s; references: %s" % (
                E, S, "phi / expected fitted on the device (BASELINE configs[2])" if (args.fit or args.deep) else "phi / expected given (configs[1])",
                "sums of 20 - 32 other samples of the cohort (deep aggregate references, the reference's workflow)" if args.deep else "the synthetic reference matrix (K = 8)"),
-           "emit_mode": args.emit_mode, "columns_compared": S,
+           "emit_mode": args.emit_mode, "device_counts": "uint16" if args.counts_bits == 16 else "int32", "columns_compared": S,
            "compared_against": "checker, libm flavour (bit-identical to the reference's compiled lnbeta; C_hmm restated), given the (phi, expected) the device used",
            "cells": E * S, "loglik_values": 3 * E * S,
            "loglik_beyond_1e-10_relative": sum(r[0] for r in res),
