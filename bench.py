@@ -491,6 +491,110 @@ def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps, opts={}):
             "unit": "exons*samples/s", **res}
 
 
+def dropin_leg(ed, chrom_off, start, end, test_h, ref_h, phi, p, reps=5):
+    """The two reference-shaped entries at the granularity the UNCHANGED S4 surface calls them (reference R/class_definition.R:184-189: one
+    .Call get_loglike_matrix per sample; R/tools.R:97 <- R/class_definition.R:354-374: one .Call C_hmm per chromosome and sample), host
+    arrays in, host arrays out, timed at the C-ABI (ctypes, arrays made beforehand) next to the CPU port doing the same call.  `first` = the
+    call that computes a chain's log-transitions on the host (exp / log of libm: the reference's own calls), `repeat` = the following
+    samples' calls for the same chromosome, which find them remembered (csrc/eddropin.inc)."""
+    import ctypes as C
+    from exomedepth_amd._lib import check, lib
+    from oracle import edoracle as eo
+    eo.build()
+    L, OL = lib(), eo.lib()
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    E = test_h.shape[0]
+    med = lambda xs: float(np.median(xs)) * 1e3
+    out = {}
+    # ---- get_loglike_matrix on all exons of one sample
+    tot = np.ascontiguousarray(test_h[:, 0] + ref_h[:, 0], dtype=np.int32); obs = np.ascontiguousarray(test_h[:, 0], dtype=np.int32)
+    ph = np.full(E, float(phi[0])); ex = np.full(E, float(p[0]))
+    ll = np.empty((3, E)); nerr = C.c_int64(0)
+    tg = []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        check(L.ed_get_loglike_matrix(vp(ph), vp(ex), vp(tot), vp(obs), E, 1.0, vp(ll), C.byref(nerr)))
+        tg.append(time.perf_counter() - t0)
+    oll = np.empty((3, E))
+    tc = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        OL.edo_get_loglike_matrix(eo.LIBM, ph, ex, tot, obs, E, 1.0, oll)
+        tc.append(time.perf_counter() - t0)
+    port, _ = eo.get_loglike_matrix(ph, ex, tot, obs, 1.0, eo.PORTABLE)
+    out["get_loglike_matrix"] = {"rows": E, "ms_first_call": tg[0] * 1e3, "ms": med(tg[1:]), "cpu_port_ms": med(tc),
+                                 "bit_mismatches_vs_checker": int(np.sum(ll.T.view(np.int64) != np.ascontiguousarray(port).view(np.int64)))}
+    # ---- C_hmm: the padded chains CallCNVs builds (R/class_definition.R:364-368), HMM column order
+    t = 1e-4
+    Tc = np.ascontiguousarray(np.array([[1 - t, t / 2, t / 2], [.5, .5, 0], [.5, 0, .5]]).T.ravel())
+    Lcnv = 50000.0
+    def chain(c, lmat):
+        lo, hi = int(chrom_off[c]), int(chrom_off[c + 1])
+        loc = np.vstack([[-np.inf, 0, -np.inf], lmat[lo:hi], [-100, 0, -100]])[:, [1, 0, 2]]
+        pos = np.concatenate([[start[lo] - 2 * Lcnv], start[lo:hi], [end[hi - 1] + 2 * Lcnv]]).astype(np.int32)
+        return np.ascontiguousarray(loc.T.ravel()), pos
+    lens = np.diff(np.asarray(chrom_off))
+    chroms = {"longest": int(np.argmax(lens)), "median": int(np.argsort(lens)[len(lens) // 2])}
+    def gpu_hmm(llc, pos, path, calls, nc):
+        check(L.ed_hmm(3, pos.size, vp(Tc), vp(llc), vp(pos), Lcnv, vp(path), vp(calls), pos.size, C.byref(nc)))
+    def cpu_hmm(llc, pos, path, calls):
+        return OL.edo_hmm(3, pos.size, Tc, llc, pos, Lcnv, path, calls, pos.size)
+    for name, c in chroms.items():
+        llc, pos = chain(c, ll.T)
+        n = pos.size
+        path = np.empty(n); calls = np.zeros((4, n)); nc = C.c_int64(0)
+        opath = np.empty(n); ocalls = np.zeros((n, 4))
+        L.ed_dropin_release()
+        first, rep = [], []
+        for r in range(reps):
+            q = pos.copy(); q[-1] += r + 1                      # (a chain not seen before: its log-transitions are computed)
+            t0 = time.perf_counter(); gpu_hmm(llc, q, path, calls, nc); first.append(time.perf_counter() - t0)
+        gpu_hmm(llc, pos, path, calls, nc)
+        for r in range(reps):
+            t0 = time.perf_counter(); gpu_hmm(llc, pos, path, calls, nc); rep.append(time.perf_counter() - t0)
+        tcpu = []
+        for r in range(reps):
+            t0 = time.perf_counter(); onc = cpu_hmm(llc, pos, opath, ocalls); tcpu.append(time.perf_counter() - t0)
+        out["hmm_" + name + "_chromosome"] = {"observations": int(n), "ms_first": med(first[1:] if reps > 1 else first), "ms_repeat": med(rep), "cpu_port_ms": med(tcpu),
+                                              "path_mismatches_vs_checker": int(np.sum(path != opath)), "calls": int(nc.value), "calls_checker": int(onc)}
+    # ---- one sample through the unchanged surface: 1 + C calls; two samples, so that the second finds every chain remembered
+    seq = []
+    for sidx in (0, 1):
+        tot = np.ascontiguousarray(test_h[:, sidx] + ref_h[:, sidx], dtype=np.int32); obs = np.ascontiguousarray(test_h[:, sidx], dtype=np.int32)
+        ph = np.full(E, float(phi[sidx])); ex = np.full(E, float(p[sidx]))
+        if sidx == 0:
+            L.ed_dropin_release()
+        t0 = time.perf_counter()
+        check(L.ed_get_loglike_matrix(vp(ph), vp(ex), vp(tot), vp(obs), E, 1.0, vp(ll), C.byref(nerr)))
+        t1 = time.perf_counter()
+        chains = [chain(c, ll.T) for c in range(len(lens)) if lens[c] > 0]          # (R's rbind / c() of :364-368: not the library's time)
+        bufs = [(np.empty(pz.size), np.zeros((4, pz.size))) for _, pz in chains]
+        nc = C.c_int64(0)
+        t2 = time.perf_counter()
+        ncalls = 0
+        for (llc, pz), (pa, ca) in zip(chains, bufs):
+            gpu_hmm(llc, pz, pa, ca, nc); ncalls += nc.value
+        t3 = time.perf_counter()
+        t4 = time.perf_counter()
+        OL.edo_get_loglike_matrix(eo.LIBM, ph, ex, tot, obs, E, 1.0, oll)
+        t5 = time.perf_counter()
+        ocalls_n = 0; mism = 0
+        t6 = time.perf_counter()
+        for (llc, pz), (pa, ca) in zip(chains, bufs):
+            op = np.empty(pz.size); oc = np.zeros((pz.size, 4))
+            ocalls_n += cpu_hmm(llc, pz, op, oc)
+            mism += int(np.sum(op != pa))
+        t7 = time.perf_counter()
+        seq.append({"get_loglike_matrix_ms": (t1 - t0) * 1e3, "hmm_calls": len(chains), "hmm_ms_total": (t3 - t2) * 1e3, "calls": int(ncalls),
+                    "cpu_port_get_loglike_matrix_ms": (t5 - t4) * 1e3, "cpu_port_hmm_ms_total": (t7 - t6) * 1e3, "cpu_port_calls": int(ocalls_n),
+                    "path_mismatches_vs_checker_given_the_device_matrix": mism})
+    out["one_sample_sequence"] = {"first_sample": seq[0], "next_sample": seq[1],
+                                  "note": "1 + %d calls per sample; the CPU port's Viterbi runs on the device's likelihood matrix here (same input both sides); "
+                                          "its allocation of the outputs is inside its time, the device side's is not" % seq[0]["hmm_calls"]}
+    L.ed_dropin_release()
+    return out
+
+
 def multi_device_main(args):
     """--driver multi-device: N devices from one process (ed_multi_*, csrc/edmulti.inc).  Weak scaling: every device gets --samples columns.
     The entry is the host-level one (the .Call boundary hands over host matrices), so a step here INCLUDES the upload of its counts from
@@ -615,6 +719,8 @@ def main():
                     "2 = one lane, round 4's form: 4.17-4.20; 8: 4.2)")
     ap.add_argument("--workflow-reps", type=int, default=3, help="after the timed region (N = 1): the reference's workflow for one cohort end to end -- "
                     "upload, reference sets, calls -- reported under extra.workflow; 0: skip")
+    ap.add_argument("--dropin", type=int, default=1, help="1 (default, N = 1): time the two reference-shaped entries (ed_get_loglike_matrix on all exons of a sample, ed_hmm on the "
+                    "longest / a median chromosome, the 1 + 24-call sequence of one sample) next to the CPU port: extra.dropin")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the CPU baseline with one sample per host core "
                     "(process-level parallelism; reported inside cpu_baseline.all_cores)")
@@ -955,6 +1061,9 @@ def main():
     workflow = None
     if args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64 and (world == 1 or use_pg):
         workflow = leg(workflow_leg, ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode], world, rank, eddist)
+    dropin = None
+    if world == 1 and args.dropin and plain and not args.fused:
+        dropin = leg(dropin_leg, ed, chrom_off, start, end, test[:, :2].cpu().numpy(), ref[:, :2].cpu().numpy(), phi.cpu().numpy(), p.cpu().numpy())
     other_modes = None
     if world == 1 and args.strict_steps > 0 and plain and not args.fused and use_cohort and args.emit_mode == "tables":
         other_modes = {"strict": leg(mode_leg, ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {}),
@@ -1035,7 +1144,7 @@ def main():
                                 "lists ran out (every cell looked at again)",
             "verify": verify,
             "fit_concordance": fit_conc,
-            "extra": {"config1": config1, "workflow": workflow, "other_modes": other_modes},
+            "extra": {"config1": config1, "workflow": workflow, "other_modes": other_modes, "dropin": dropin},
         }
         if staged:
             if "value_with_h2d" in staged:

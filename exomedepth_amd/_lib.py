@@ -51,6 +51,7 @@ SYMBOLS = [
     ("ed_get_loglike_matrix", C.c_int, [_vp, _vp, _vp, _vp, _i64, _dbl, _vp, C.POINTER(_i64)]),
     ("ed_get_loglike_matrix_messages", C.c_int, [_vp, _vp, _vp, _vp, _i64, _dbl, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ed_hmm", C.c_int, [_i32, _i32, _vp, _vp, _vp, _dbl, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("ed_dropin_release", None, []),
     ("ed_plan_create", C.c_int, [C.POINTER(_vp), C.c_int, _i64, _i32, _vp, _vp, _vp, _dbl, _dbl]),
     ("ed_plan_destroy", None, [_vp]),
     ("ed_plan_n_exons", _i64, [_vp]),

@@ -655,61 +655,6 @@ k_emit_verify(const int32_t* __restrict__ test, const int32_t* __restrict__ ref,
 
 // ---- Viterbi --------------------------------------------------------------------------------
 
-// One forward step (src/hmm.cpp:68-88).  v[] are the previous scores, e[] the three emissions in HMM
-// order (normal, deletion, duplication), lt[j*3+k] = log(trans k->j) for this exon gap (host-built).
-// Candidate order and the strict '>' reproduce the reference's tie-breaking (first maximum wins).
-// Back-pointer of a state no candidate improves on is 0 (the reference leaves -1 there, which it can
-// only ever use as an out-of-bounds index: see include/exomedepth_amd.h).
-__device__ __forceinline__ unsigned vit_step(double v[3], const double e[3], const double* __restrict__ lt)
-{
-  double nv[3];
-  unsigned bp = 0;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    double best = -HUGE_VAL;
-    unsigned fw = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double cand = (e[j] + v[k]) + lt[j * 3 + k];
-      if (cand > best) {
-        best = cand;
-        fw = k;
-      }
-    }
-    if (e[j] == -HUGE_VAL) fw = 0;
-    nv[j] = best;
-    bp |= fw << (2 * j);
-  }
-  v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2];
-  return bp;
-}
-
-// Run-length summary of one chain (src/hmm.cpp:104-126), quirks kept: `start` is only (re)set when
-// leaving state 0, `nexons` only resets when a call is pushed.  tb(i) returns the state of padded
-// observation i (0..last).  emit(start_i, end_i, type, nexons) receives 0-based padded indices.
-template <class TB, class EMIT>
-__device__ __forceinline__ int summarise_chain(int64_t last, TB tb, EMIT emit)
-{
-  int64_t start = -1;
-  int nexons = 0, current = 0, ncalls = 0;
-  int prev = tb(0);
-  for (int64_t i = 1; i <= last; ++i) {
-    const int cur = tb(i);
-    if (prev != cur) {
-      if (current == 0) start = i;
-      if (current != 0) {
-        emit(start, i - 1, current, nexons, ncalls);
-        ++ncalls;
-        nexons = 0;
-      }
-    }
-    if (cur != 0) ++nexons;
-    current = cur;
-    prev = cur;
-  }
-  return ncalls;
-}
-
 // ---- batched chains -------------------------------------------------------------------------
 // A chain (one sample x one chromosome) is strictly sequential: the max-plus recurrence is evaluated in
 // the reference's association order, so there is no scan over exons.  The parallelism inside a chain
@@ -1271,40 +1216,6 @@ __global__ void k_call_info(const ed_call* __restrict__ calls, int64_t ncalls, c
   o.reads_observed = obs;
   o.reads_ratio = signif3((double)obs / (double)o.reads_expected);
   out[r] = o;
-}
-
-// Single chain with caller-supplied probabilities: the reference's C_hmm signature.
-//   proba nobs x 3 column-major (HMM order), lt [(nobs-1)][9], path_out double[nobs]
-//   calls_out column-major cap x 4, ncalls_out
-// One lane does the sequential work (a drop-in for fidelity, not a throughput path).
-__global__ void k_viterbi_single(const double* __restrict__ proba, const double* __restrict__ lt, int64_t nobs,
-                                 uint8_t* __restrict__ bp, double* __restrict__ path_out,
-                                 double* __restrict__ calls_out, int64_t cap, int64_t* __restrict__ ncalls_out)
-{
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  double v[3] = {0., -HUGE_VAL, -HUGE_VAL};
-  for (int64_t i = 1; i < nobs; ++i) {
-    const double e[3] = {proba[i], proba[nobs + i], proba[2 * nobs + i]};
-    bp[i] = (uint8_t)vit_step(v, e, lt + (i - 1) * 9);
-  }
-  int cur = 0;  // last observation forced to state 0 (src/hmm.cpp:96)
-  for (int64_t i = nobs - 1; i >= 1; --i) {
-    const unsigned b = bp[i];
-    bp[i] = (uint8_t)cur;
-    cur = (b >> (2 * cur)) & 3;
-  }
-  bp[0] = (uint8_t)cur;
-  for (int64_t i = 0; i < nobs; ++i) path_out[i] = (double)bp[i];
-  auto tb = [&](int64_t i) -> int { return (int)bp[i]; };
-  auto emit = [&](int64_t st, int64_t en, int type, int nexons, int k) {
-    if (k < cap) {
-      calls_out[0 * cap + k] = (double)(st + 1);
-      calls_out[1 * cap + k] = (double)(en + 1);
-      calls_out[2 * cap + k] = (double)type;
-      calls_out[3 * cap + k] = (double)nexons;
-    }
-  };
-  *ncalls_out = summarise_chain(nobs - 1, tb, emit);
 }
 
 // ---- K5: per-sample beta-binomial fit -------------------------------------------------------
@@ -1998,35 +1909,7 @@ try {
 }
 ED_CATCH("ed_eval_sf")
 
-// ---- drop-in 1: get_loglike_matrix ---------------------------------------------------------
-ED_EXPORT int ed_get_loglike_matrix(const double* phi, const double* expected, const int32_t* total,
-                                    const int32_t* observed, int64_t n, double mixture, double* out,
-                                    int64_t* n_gsl_errors)
-try {
-  if (n < 0 || (n > 0 && (!phi || !expected || !total || !observed || !out)))
-    return ed_fail(ED_ERR_INVALID, "ed_get_loglike_matrix: NULL buffer or negative n");
-  if (int rc = require_device()) return rc;
-  if (n_gsl_errors) *n_gsl_errors = 0;
-  if (n == 0) return ED_OK;
-  DevBuf dphi, dexp, dtot, dobs, dout, dnerr;
-  HIP_TRY(dphi.alloc(n * 8)); HIP_TRY(dexp.alloc(n * 8)); HIP_TRY(dtot.alloc(n * 4)); HIP_TRY(dobs.alloc(n * 4));
-  HIP_TRY(dout.alloc(n * 24)); HIP_TRY(dnerr.alloc(8));
-  HIP_TRY(hipMemcpy(dphi.p, phi, n * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dexp.p, expected, n * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dtot.p, total, n * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dobs.p, observed, n * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(dnerr.p, 0, 8));
-  hipLaunchKernelGGL(k_emit_rows, dim3((unsigned)((n + kEmitBlock - 1) / kEmitBlock)), dim3(kEmitBlock), 0, 0,
-                     dphi.as<double>(), dexp.as<double>(), dtot.as<int32_t>(), dobs.as<int32_t>(), n, mixture,
-                     dout.as<double>(), dnerr.as<unsigned long long>());
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, dout.p, n * 24, hipMemcpyDeviceToHost));
-  unsigned long long ne = 0;
-  HIP_TRY(hipMemcpy(&ne, dnerr.p, 8, hipMemcpyDeviceToHost));
-  if (n_gsl_errors) *n_gsl_errors = (int64_t)ne;
-  return ED_OK;
-}
-ED_CATCH("ed_get_loglike_matrix")
+#include "eddropin.inc"      // the two reference-shaped entries: ed_get_loglike_matrix, ed_hmm
 
 // The text the reference prints while it computes the same matrix: one gsl_error() call = two Rprintf lines
 // (src/error.c:45-48), in the order the reference makes them (rows in order; deletion, normal, duplication;
@@ -2085,35 +1968,6 @@ try {
   return ED_OK;
 }
 ED_CATCH("ed_get_loglike_matrix_messages")
-
-// ---- drop-in 2: C_hmm ----------------------------------------------------------------------
-ED_EXPORT int ed_hmm(int32_t nstates, int32_t nobs, const double* transitions, const double* probabilities,
-                     const int32_t* positions, double expected_length, double* path_out, double* calls_out,
-                     int64_t calls_cap, int64_t* n_calls)
-try {
-  if (nstates != 3) return ed_fail(ED_ERR_INVALID, "ERROR: The code must assume 3 states");  // src/hmm.cpp:37-40
-  if (nobs < 0 || calls_cap < 0 || !n_calls || (nobs > 0 && (!transitions || !probabilities || !positions || !path_out)))
-    return ed_fail(ED_ERR_INVALID, "ed_hmm: bad arguments");
-  if (calls_cap > 0 && !calls_out) return ed_fail(ED_ERR_INVALID, "ed_hmm: calls_out is NULL");
-  if (int rc = require_device()) return rc;
-  *n_calls = 0;
-  if (nobs == 0) return ED_OK;
-  std::vector<double> lt((size_t)std::max<int64_t>(nobs - 1, 1) * 9);
-  fill_log_transitions(transitions, expected_length, positions, nobs, lt.data());
-  DevBuf dproba, dlt, dbp, dpath, dcalls, dn;
-  HIP_TRY(dproba.alloc((size_t)nobs * 24)); HIP_TRY(dlt.alloc(lt.size() * 8)); HIP_TRY(dbp.alloc(nobs));
-  HIP_TRY(dpath.alloc((size_t)nobs * 8)); HIP_TRY(dcalls.alloc((size_t)calls_cap * 32)); HIP_TRY(dn.alloc(8));
-  HIP_TRY(hipMemcpy(dproba.p, probabilities, (size_t)nobs * 24, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dlt.p, lt.data(), lt.size() * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_viterbi_single, dim3(1), dim3(64), 0, 0, dproba.as<double>(), dlt.as<double>(), (int64_t)nobs,
-                     dbp.as<uint8_t>(), dpath.as<double>(), dcalls.as<double>(), calls_cap, dn.as<int64_t>());
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(path_out, dpath.p, (size_t)nobs * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(n_calls, dn.p, 8, hipMemcpyDeviceToHost));
-  if (calls_cap > 0) HIP_TRY(hipMemcpy(calls_out, dcalls.p, (size_t)calls_cap * 32, hipMemcpyDeviceToHost));
-  return ED_OK;
-}
-ED_CATCH("ed_hmm")
 
 // ---- plan ----------------------------------------------------------------------------------
 ED_EXPORT int ed_plan_create(ed_plan** plan, int device, int64_t n_exons, int32_t n_chrom, const int32_t* chrom_off,

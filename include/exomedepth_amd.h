@@ -81,6 +81,11 @@ int ed_hmm(int32_t nstates, int32_t nobs, const double* transitions, const doubl
            const int32_t* positions, double expected_length, double* path_out, double* calls_out, int64_t calls_cap,
            int64_t* n_calls);
 
+/* The two entries above keep one process-wide scratch between calls -- a device block, a pinned host block, a stream, and the host-computed
+ * log-transitions (src/hmm.cpp:62-79) of the chains seen last: CallCNVs calls C_hmm with the same positions for every sample
+ * (R/class_definition.R:354-374).  Calls are serialised (R's API is single-threaded).  This releases all of it; the next call starts afresh. */
+void ed_dropin_release(void);
+
 /* =====================================================================================
  * 2. Batched interface (device-resident)
  * ===================================================================================== */
