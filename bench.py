@@ -173,8 +173,23 @@ def _device_view(torch, eddist, ptr, shape, typestr, dev):
     return torch.as_tensor(eddist._DevicePointer(ptr, shape, typestr), device=dev)
 
 
+def interval_union(iv):
+    """(total length of the union, sum of the lengths) of (start, end) intervals"""
+    iv = sorted((float(a), float(b)) for a, b in iv)
+    if not iv:
+        return 0.0, 0.0
+    union, (cs, ce) = 0.0, iv[0]
+    for a, b in iv[1:]:
+        if a > ce:
+            union += ce - cs
+            cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    return union + (ce - cs), sum(b - a for a, b in iv)
+
+
 def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_batches, test, ref, phi, p, phi_fit, p_fit, fitted,
-                          chrom_off, start, end, k, tables=False):
+                          chrom_off, start, end, k, tables=False, max_slabs=None):
     """k columns of each of the last slabs in flight against the CPU checker (oracle/, the checker -- never the thing timed):
     the bits of the likelihood matrix vs its portable flavour, Viterbi states and call rows vs its Viterbi run on its own matrix,
     given the (phi, expected) the device used for that slab."""
@@ -188,7 +203,7 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
                "discordant_calls": 0, "slabs": 0}
     slabs = []
     if co is not None:
-        for t in range(max(0, last_ticket - n_batches + 1), last_ticket + 1):
+        for t in range(max(0, last_ticket - (min(n_batches, max_slabs) if max_slabs else n_batches) + 1), last_ticket + 1):
             b, pp, pe = co.batch(t)
             b.n_samples = S
             slabs.append((b, _device_view(torch, eddist, pp, (S,), "<f8", dev).cpu().numpy(), _device_view(torch, eddist, pe, (S,), "<f8", dev).cpu().numpy()))
@@ -244,9 +259,9 @@ NOTE_STRICT = ("FP64-VALU-bound kernel (no MFMA applies; SURVEY.md 0.5): the HBM
 NOTE_TABLES = ("table-driven emissions, sample-major (k_emit_tab_sm): ~155 VALU lane-instructions per cell, the hot 85-99 % of a sample's "
                "log-gamma difference tables in LDS -- a memory-streaming kernel: reads the counts (8 B/cell) and writes the [S][3][E] f64 "
                "likelihood matrix (24 B/cell) that k_viterbi_sm reads back, i.e. 33 B/cell algorithmic in the materialised form against the "
-               "9 B/cell of `achieved` (SURVEY.md 8d).  kernel_ms: HIP events recorded by the library around the emission launches on the "
-               "stream they run on (one launch per step), live = sharing the chip with the previous slab's Viterbi chains, the next slab's fit and -- with "
-               "two lanes, the default -- the OTHER lane's emission launch (roofline.launch_overlap); kernel_ms_alone = the same launch with the GPU to itself")
+               "9 B/cell of `achieved` (SURVEY.md 8d).  kernel_ms: the chip's time per emission launch (see kernel_ms_is), live = sharing the chip with the "
+               "previous slabs' Viterbi chains and the next slabs' fits and table builds; kernel_ms_own = a launch's own duration (with three lanes, the default, "
+               "two or three emission launches are in flight at a time); kernel_ms_alone = the same launch with the GPU to itself")
 
 
 def mode_opts(args):
@@ -491,6 +506,48 @@ def config1_leg(ed, torch, plan, test, ref, phi, p, E, steps, opts={}):
             "unit": "exons*samples/s", **res}
 
 
+def regime_leg(ed, eddist, torch, dev, plan, chrom_off, start, end, E, S, depth, fit, opts, n_batches, steps, seed, verify_columns):
+    """The headline's step in another regime of the synthetic generator -- another sequencing depth (reads per exon and sample; the aggregate
+    references are 8 x deeper) or another slab width -- with the headline's cohort options: ms per step, what the tables left to the strict
+    arithmetic, the chip time of the emission launches, and the same check against the CPU checker as the headline's `verify`."""
+    from exomedepth_amd import synth
+    test, ref, p, phi = synth.counts_torch(chrom_off, S, dev, seed=seed, mean_depth=depth)
+    lay1 = opts.get("counts_layout") == 1
+    t_in, r_in = (test.t().contiguous(), ref.t().contiguous()) if lay1 else (test, ref)
+    o = dict(opts)
+    if n_batches not in (4, 6, 8):
+        o.pop("lanes", None)
+    co = ed.Cohort(plan, S, n_batches, **o)
+    sub = (lambda: co.submit(t_in, r_in, n_samples=S)) if fit else (lambda: co.submit(t_in, r_in, phi=phi, expected=p, n_samples=S))
+    for _ in range(n_batches + 2):
+        tk = sub()
+    co.drain()
+    torch.cuda.synchronize()
+    co.set_option("timing", 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tk = sub()
+    co.drain()
+    el = time.perf_counter() - t0
+    b, _, _ = co.batch(tk)
+    b.n_samples = S
+    tstats = b.table_stats() if o.get("emit_mode") else None
+    stage, nr, _ = co.stage_ms_total()
+    union, own = interval_union(co.emission_intervals())
+    ver = None
+    if verify_columns > 0:
+        ver = verify_against_oracle(ed, eddist, torch, dev, co, [], tk, n_batches, test, ref, phi, p, None, None, bool(fit), chrom_off, start, end,
+                                    verify_columns, tables=bool(o.get("emit_mode")), max_slabs=2)
+        ver.pop("what", None)
+    co.close()
+    cells = float(E) * S
+    ms = el / steps * 1e3
+    return {"depth": depth, "samples": S, "ms_per_step": ms, "value": cells * steps / el, "ns_per_cell": ms * 1e6 / cells,
+            "emission_ms_chip": union / max(nr, 1), "emission_ms_own": own / max(nr, 1),
+            "stage_ms": {k: v / max(nr, 1) for k, v in stage.items()},
+            "table_stats": tstats, "cold_share": (tstats["n_cold_cells"] / cells if tstats else None), "verify": ver}
+
+
 def dropin_leg(ed, chrom_off, start, end, test_h, ref_h, phi, p, reps=5):
     """The two reference-shaped entries at the granularity the UNCHANGED S4 surface calls them (reference R/class_definition.R:184-189: one
     .Call get_loglike_matrix per sample; R/tools.R:97 <- R/class_definition.R:354-374: one .Call C_hmm per chromosome and sample), host
@@ -719,6 +776,8 @@ def main():
                     "2 = one lane, round 4's form: 4.17-4.20; 8: 4.2)")
     ap.add_argument("--workflow-reps", type=int, default=3, help="after the timed region (N = 1): the reference's workflow for one cohort end to end -- "
                     "upload, reference sets, calls -- reported under extra.workflow; 0: skip")
+    ap.add_argument("--regimes", type=int, default=1, help="1 (default, N = 1, the default workload only): the headline's step at depths 25 / 400 / 1600 and at 64 / 256 samples "
+                    "per slab, each with table statistics and the check against the CPU checker: extra.regimes")
     ap.add_argument("--dropin", type=int, default=1, help="1 (default, N = 1): time the two reference-shaped entries (ed_get_loglike_matrix on all exons of a sample, ed_hmm on the "
                     "longest / a median chromosome, the 1 + 24-call sequence of one sample) next to the CPU port: extra.dropin")
     ap.add_argument("--lib-variant", default="", help="load exomedepth_amd/libedcore_<name>.so instead of libedcore.so (experiments only)")
@@ -1004,6 +1063,14 @@ def main():
     assert n_timed == args.steps or os.environ.get("ED_BENCH_NO_STAGE_TIMING") == "1", (n_timed, args.steps)
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
     n_launch = max(1, n_launch_of())   # emission launches per step
+    # chip time of the emission launches: with several lanes they run side by side, so the union of their intervals (HIP events of the library on
+    # the streams the launches run on, relative to one reference event) is what the chip spends on them, their mean length a launch's own duration
+    emit_union_ms = emit_own_ms = None
+    if use_cohort and os.environ.get("ED_BENCH_NO_STAGE_TIMING") != "1":
+        iv = co.emission_intervals()
+        if len(iv) == args.steps:
+            u, o_ = interval_union(iv)
+            emit_union_ms, emit_own_ms = u / args.steps, o_ / args.steps
     # (outside the timed region) the emission launches with the GPU to themselves: one slab, given phi, nothing queued on
     # other streams -- what the kernel takes when it does not host the next slab's fit and the previous slab's chains
     alone_ms = None
@@ -1064,6 +1131,12 @@ def main():
     dropin = None
     if world == 1 and args.dropin and plain and not args.fused:
         dropin = leg(dropin_leg, ed, chrom_off, start, end, test[:, :2].cpu().numpy(), ref[:, :2].cpu().numpy(), phi.cpu().numpy(), p.cpu().numpy())
+    regimes = None
+    if world == 1 and args.regimes and use_cohort and plain and not args.fused and args.emit_mode == "tables" and (E, S, int(args.depth)) == (200_000, 1024, 100):
+        regimes = []
+        for (dpt, ss) in ((25.0, 1024), (400.0, 1024), (1600.0, 1024), (100.0, 256), (100.0, 64)):
+            regimes.append(leg(regime_leg, ed, eddist, torch, dev, plan, chrom_off, start, end, E, ss, dpt, args.fit, {k: v for k, v in opts_headline.items() if k != "timing"},
+                               n_batches, 8, 20250620 + 3 + int(dpt) + ss, 2))
     other_modes = None
     if world == 1 and args.strict_steps > 0 and plain and not args.fused and use_cohort and args.emit_mode == "tables":
         other_modes = {"strict": leg(mode_leg, ed, torch, plan, test, ref, S, args.strict_steps, args.fit, phi, p, {}),
@@ -1083,7 +1156,12 @@ def main():
 
     if rank == 0:
         kernel = "k_emit_viterbi" if args.fused else ({"strict": "k_emit_batch", "tables-tile": "k_emit_tab", "tables": "k_emit_tab_sm"}[args.emit_mode] if plain else "k_emit_bins")
-        t_emit = stage_ms["emissions"] * 1e-3
+        # kernel_ms: the CHIP's time per emission launch over the timed steps = union of the launches' intervals / launches.  One pipeline: that is the
+        # launch's own duration.  Several lanes (the default): the emission launches of consecutive slabs run side by side, a launch's own duration
+        # (kernel_ms_own, what a kernel trace's average shows) is longer than the chip spends on it, and dividing bytes by it would measure the overlap.
+        own_ms_step = stage_ms["emissions"]
+        chip_ms_step = emit_union_ms if emit_union_ms else own_ms_step
+        t_emit = chip_ms_step * 1e-3
         achieved = ALGO_BYTES_PER_CELL * E * S / t_emit / 1e9 if t_emit > 0 else 0.0
         kernel_cells_per_s = (E * S / t_emit) if t_emit else 0.0
         meta, why_not = matching_profile()
@@ -1096,41 +1174,47 @@ def main():
                                        % (meta["tag"], json.dumps(w)))
         pmc = pmc_figures(meta, kernel, float(E) * S, kernel_cells_per_s) if meta else None
         traffic = pmc.get("traffic_bytes_per_step") / n_launch if pmc and "traffic_bytes_per_step" in pmc else None
+        step_ms = elapsed / args.steps * 1e3
+        gbs = lambda ms: (ALGO_BYTES_PER_CELL * E * S / (ms * 1e-3) / 1e9) if ms else None
+        frac_of = lambda ms: (gbs(ms) / HBM_PEAK_GBS) if ms else None
         out = {
             "metric": "exons*samples/s through betabinom emissions + Viterbi" + (" + dispersion fit" if args.fit else ""),
             "value": value, "unit": "exons*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2] geometry: %d exons x %d samples per GPU, %d chromosomes, "
                                    "phi %s, transition.probability 1e-4, expected.CNV.length 5e4"
                                    % (E, S, C, "fitted on device" if args.fit else "given per sample (fixed)"),
                        "exons": E, "samples_per_gpu": S, "samples_total": S * world, "fit": bool(args.fit), "fit_mode": args.fit_mode, "emit_mode": args.emit_mode, "counts_layout": ("[samples][exons]" if args.counts_layout == 1 else "[exons][samples]"), "counts_bits": args.counts_bits, "fused": bool(args.fused), "phi_bins": args.phi_bins, "covariates": args.cov,
-                       "batches_in_flight": n_batches, "driver": ("cohort (ed_cohort_submit: the library's own streams and batch rotation)" if use_cohort else "python (torch streams)"),
+                       "depth": args.depth, "batches_in_flight": n_batches, "driver": ("cohort (ed_cohort_submit: the library's own streams and batch rotation)" if use_cohort else "python (torch streams)"),
                        "parallelism": "samples sharded, %d rank(s); call tables gathered to rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (pmc["profile"] + "_pmc_FETCH_SIZE/WRITE_SIZE.csv") if traffic is not None else why_not,
+                         "algorithmic_bytes_per_cell": ALGO_BYTES_PER_CELL, "launches_per_step": n_launch,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * E * S / n_launch,
+                         "kernel_ms": chip_ms_step / n_launch, "kernel_ms_per_step": chip_ms_step,
+                         "kernel_ms_is": ("union of the emission launches' intervals over the timed steps / launches (HIP events of the library on the streams the launches "
+                                          "run on: ed_cohort_emission_intervals) = the chip's time per launch; <= ms_per_step by construction" if emit_union_ms
+                                          else "mean duration of the emission launches (HIP events of the library on the stream they run on)"),
+                         "kernel_ms_own": own_ms_step / n_launch,
+                         "launches_in_flight": (own_ms_step / chip_ms_step if chip_ms_step else None),
+                         "lanes": (opts.get("lanes", 1) if use_cohort else 1),
+                         "kernel_ms_alone": alone_ms,
+                         "frac_own": frac_of(own_ms_step), "frac_alone": frac_of(alone_ms), "frac_step": frac_of(step_ms),
+                         "kernel_cells_per_s": kernel_cells_per_s,
                          "step_traffic_bytes": (pmc.get("step_traffic_bytes") if pmc else None),
                          "step_traffic_over_algorithmic": (pmc["step_traffic_bytes"] / (ALGO_BYTES_PER_CELL * float(E) * S) if pmc and pmc.get("step_traffic_bytes") else None),
                          "step_traffic_GBps": (pmc["step_traffic_bytes"] / (elapsed / args.steps) / 1e9 if pmc and pmc.get("step_traffic_bytes") else None),
-                         "algorithmic_bytes_per_cell": ALGO_BYTES_PER_CELL, "launches_per_step": n_launch,
-                         "kernel_ms": stage_ms["emissions"] / n_launch, "kernel_ms_per_step": stage_ms["emissions"],
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * E * S / n_launch,
-                         "kernel_cells_per_s": kernel_cells_per_s,
                          "algorithmic_bytes_per_cell_with_likelihood_matrix": 33,
                          "frac_with_likelihood_matrix": (33 * E * S / t_emit / 1e9 / HBM_PEAK_GBS) if t_emit > 0 else None,
                          "frac_alone_with_likelihood_matrix": (33 * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
-                         "kernel_ms_alone": alone_ms,
-                         "launch_overlap": {"lanes": (opts.get("lanes", 1) if use_cohort else 1),
-                                            "from_profile": (meta.get("emission_overlap") if meta else None),
-                                            "frac_union": ((ALGO_BYTES_PER_CELL * E * S / n_launch / (meta["emission_overlap"]["union_ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                                                           if meta and meta.get("emission_overlap") else None),
-                                            "frac_step": ALGO_BYTES_PER_CELL * E * S / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-                                            "note": "with more than one lane the emission launches of consecutive slabs run side by side: `achieved` / `frac` divide a launch's "
-                                                    "bytes by ITS duration (what the contract asks for), during which it shares the chip with another emission launch most of the "
-                                                    "time -- kernel_ms_per_step exceeds ms_per_step.  frac_union divides by the union of the launches' intervals per launch "
-                                                    "(kernel trace of the matching profile), frac_step by the whole step, frac_alone by the launch with the chip to itself"},
-                         "frac_alone": (ALGO_BYTES_PER_CELL * E * S / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
+                         "profile": ({"tag": meta["tag"], "timed_launches": meta.get("emission_overlap"),
+                                      "reproduce": "profiles/%s_kernel_stats_timed.csv: bytes per launch / union_ms_per_launch of %s / 8 TB/s = frac; its mean_ms = kernel_ms_own"
+                                                   % (meta["tag"], kernel)} if meta else None),
+                         "frac_note": "frac: a launch's algorithmic bytes over the chip's time for it (kernel_ms).  frac_own: over the launch's own duration -- with several "
+                                      "lanes in flight that measures how many launches share the chip (launches_in_flight), not the kernel.  frac_alone: the same "
+                                      "launch with the GPU to itself.  frac_step: the whole step (ms_per_step) against the same bytes",
                          "valu": pmc if pmc else why_not,
                          "note": (NOTE_TABLES if args.emit_mode == "tables" and plain else NOTE_STRICT)},
             "stage_ms": stage_ms,
@@ -1144,7 +1228,12 @@ def main():
                                 "lists ran out (every cell looked at again)",
             "verify": verify,
             "fit_concordance": fit_conc,
-            "extra": {"config1": config1, "workflow": workflow, "other_modes": other_modes, "dropin": dropin},
+            "extra": {"config1": config1, "workflow": workflow, "other_modes": other_modes, "dropin": dropin,
+                      "regimes": ({"rows": regimes, "headline_row": {"depth": args.depth, "samples": S, "ms_per_step": step_ms, "ns_per_cell": step_ms * 1e6 / (float(E) * S),
+                                                                        "emission_ms_chip": chip_ms_step, "emission_ms_own": own_ms_step, "table_stats": table_stats},
+                                   "note": "the default line's step in other regimes of the synthetic generator (depth = median reads per exon and test sample; the aggregate "
+                                           "references are 8 x deeper), same cohort options, 8 timed steps each, 2 columns of the last 2 slabs checked against the CPU checker"}
+                                  if regimes else None)},
         }
         if staged:
             if "value_with_h2d" in staged:

@@ -114,9 +114,11 @@ SYMBOLS = [
     ("ed_cohort_stream", _vp, [_vp]),
     ("ed_cohort_stage_ms_total", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
     ("ed_cohort_n_emit_launches", C.c_int, [_vp]),
+    ("ed_cohort_emission_intervals", C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
     ("ed_cohort_submit_host", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _i64, _vp, _vp, _dbl, C.POINTER(_i64)]),
     ("ed_cohort_submit_host_test", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _i64, _vp, _vp, _dbl, C.POINTER(_i64)]),
     ("ed_cohort_ingest_stats", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("ed_cohort_n_wide_slabs", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_host_alloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
     ("ed_host_free", C.c_int, [_vp]),
     ("ed_cohort_run_host", C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, C.POINTER(_i64)]),

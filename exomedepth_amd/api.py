@@ -716,6 +716,22 @@ class Cohort:
         check(lib().ed_cohort_stage_ms_total(self.handle, ms, C.byref(nr), C.byref(nf)))
         return dict(zip(self.STAGES, [float(v) for v in ms])), nr.value, nf.value
 
+    def n_wide_slabs(self):
+        """host-fed int32 slabs that held a count outside 0 .. 65 535 and went up 32 bits wide (ed_cohort_n_wide_slabs)"""
+        n = C.c_int64(0)
+        check(lib().ed_cohort_n_wide_slabs(self.handle, C.byref(n)))
+        return n.value
+
+    def emission_intervals(self):
+        """option timing: (n, 2) array of (start_ms, end_ms) of the emission stage of every timed run, relative to one reference event
+        (ed_cohort_emission_intervals) -- with several lanes the launches overlap; their union is the chip time they take"""
+        n = C.c_int64(0)
+        check(lib().ed_cohort_emission_intervals(self.handle, None, 0, C.byref(n)))
+        out = np.empty((max(n.value, 0), 2), dtype=np.float32)
+        if n.value > 0:
+            check(lib().ed_cohort_emission_intervals(self.handle, _ptr(out), n.value, C.byref(n)))
+        return out
+
     def ingest_stats(self):
         b, s = C.c_double(0), C.c_double(0)
         check(lib().ed_cohort_ingest_stats(self.handle, C.byref(b), C.byref(s)))

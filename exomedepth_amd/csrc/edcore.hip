@@ -1786,6 +1786,8 @@ struct ed_batch {
                              // glm start, optim()'s defaults) on the same histograms -- ed_batch_set_fit_mode
   bool timing = false;
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t epoch = nullptr;            // (cohort pipeline, option timing) a completed event of the owner: the emission launches' start / end times are kept relative to it
+  std::vector<float>* emit_iv = nullptr; // ... appended here as (start_ms, end_ms) when a run's times are folded (ed_cohort_emission_intervals)
   bool have_run_times = false, have_fit_time = false;
   double stage_total[5] = {0, 0, 0, 0, 0};   // sums of the stage times of all timed runs / fits since timing was enabled
   float last_ms[5] = {0, 0, 0, 0, 0};        // stage times of the most recent folded run / fit (ed_batch_stage_ms)
@@ -2288,6 +2290,12 @@ static int fold_run_times(ed_batch* b)
       HIP_TRY(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
       b->stage_total[i] += ms;
       b->last_ms[i] = ms;
+    }
+    if (b->epoch && b->emit_iv) {
+      float t0 = 0.f, t1 = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t0, b->epoch, b->ev[1]));
+      HIP_TRY(hipEventElapsedTime(&t1, b->epoch, b->ev[2]));
+      b->emit_iv->push_back(t0); b->emit_iv->push_back(t1);
     }
     ++b->n_runs_timed;
     b->have_run_times = false;

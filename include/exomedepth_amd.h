@@ -496,8 +496,12 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *   "emit_mode"        0 (default) strict, 1 tables, 2 tables sample-major: ed_batch_set_emit_mode for every slab (phi_bins must be 1)
  *   "counts_layout"    0 (default): device counts [n_exons][n_samples]; 1: [n_samples][n_exons] (needs emit_mode 2): ed_cohort_submit takes
  *                      them that way, and host-fed slabs in layout 1 (R's column-major matrix) are uploaded without a transposition
- *   "counts_bits"      32 (default) / 16: ed_batch_set_counts_bits for every slab -- device-resident uint16 counts (needs counts_layout 1 and
- *                      emit_mode 2; host-fed slabs are widened to int32 on the device and do not take it)
+ *   "counts_bits"      32 (default) / 16: ed_batch_set_counts_bits for every slab of ed_cohort_submit -- device-resident uint16 counts (needs
+ *                      counts_layout 1 and emit_mode 2).  Host-fed slabs choose their device format themselves, see "host_narrow"
+ *   "host_narrow"      1 (default) / 0: host-fed slabs of a cohort with emit_mode 2 + counts_layout 1 stay 16 bits wide on the device whenever
+ *                      their counts fit -- uint16 host blocks go up as they lie, int32 blocks in pageable memory (R's integer matrices) are
+ *                      narrowed by the host threads that stage them: 2 bytes per count on the link, no widening pass.  A slab holding a count
+ *                      outside 0 .. 65 535 goes up as int32 (ed_cohort_n_wide_slabs counts them).  Same bits of every result either way
  *   "viterbi_overlap"  0 (default): one emission launch per slab, its chains afterwards; 1: ed_batch_set_viterbi_overlap(1)
  *   "tables_early"     1: a slab's per-sample constants and tables are made right behind its fit, on the fit stream; 0 (default):
  *                      between two emission launches (the same work either way: measured equal)
@@ -534,6 +538,11 @@ int ed_cohort_drain(ed_cohort* cohort);                  /* ... for everything s
 void* ed_cohort_stream(ed_cohort* cohort);               /* the pipeline's main stream (a hipStream_t) */
 /* ed_batch_stage_ms_total summed over the cohort's batch objects; launches of the emission kernel per slab */
 int ed_cohort_stage_ms_total(ed_cohort* cohort, double ms_total[5], int64_t* n_runs, int64_t* n_fits);
+/* Option "timing": (start_ms, end_ms) of the emission stage of every run timed since the option was set, relative to one reference event of the
+ * cohort.  With several lanes the emission launches of consecutive slabs run side by side: the union of these intervals is the chip time during
+ * which an emission launch was active (bench.py's roofline.kernel_ms), their mean length a launch's own duration (what a kernel trace's average
+ * shows).  out[2 * cap]; *n = pairs available, the first min(*n, cap) are written. */
+int ed_cohort_emission_intervals(ed_cohort* cohort, float* out, int64_t cap, int64_t* n);
 int ed_cohort_n_emit_launches(ed_cohort* cohort);
 
 /* ed_cohort_submit_host with only the TEST counts in host memory and the references on the device (d_ref: int32, complete when this
@@ -549,7 +558,9 @@ int ed_cohort_submit_host_test(ed_cohort* cohort, const void* test, const int32_
  *           is its first n_samples columns from the given pointer (row_stride = the cohort's width for a window of columns)
  * layout 1: the host matrix is R's n_exons x n_samples integer matrix, column-major (row_stride ignored); transposed on the
  *           device to the pipeline's sample-minor layout
- * wire 4: int32 elements; wire 2: uint16 elements, widened on the device (counts below 65536: half the PCIe bytes)
+ * wire 4: int32 elements; wire 2: uint16 elements (counts below 65536: half the PCIe bytes), widened on the device -- except in a cohort with
+ *         emit_mode 2 + counts_layout 1, where slabs whose counts fit 16 bits STAY uint16 on the device and pageable int32 blocks are narrowed
+ *         on the host while they are staged (option "host_narrow")
  * Pinned host memory (ed_host_alloc) is read by the DMA engine in place; pageable memory goes through the cohort's pinned
  * double buffer (a few host threads copy chunk k+1 while chunk k is on the link).  Uploads run on a copy stream of the
  * cohort and overlap the compute of earlier slabs.  phi / expected: DEVICE arrays or NULL (fit), as ed_cohort_submit.
@@ -557,6 +568,7 @@ int ed_cohort_submit_host_test(ed_cohort* cohort, const void* test, const int32_
 int ed_cohort_submit_host(ed_cohort* cohort, const void* test, const void* ref, int64_t n_samples, int layout, int wire,
                           int64_t row_stride, const double* d_phi, const double* d_expected, double mixture, int64_t* ticket);
 int ed_cohort_ingest_stats(ed_cohort* cohort, double* bytes, double* host_seconds);
+int ed_cohort_n_wide_slabs(ed_cohort* cohort, int64_t* n);   /* host-fed int32 slabs that held a count outside 0 .. 65 535 and went up 32 bits wide */
 int ed_host_alloc(void** hptr, size_t bytes);   /* pinned host memory */
 int ed_host_free(void* hptr);
 

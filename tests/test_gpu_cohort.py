@@ -101,6 +101,47 @@ def test_device_slabs_through_the_cohort_equal_the_batch_interface(cohort_data, 
     co.close()
 
 
+@pytest.mark.parametrize("given", [False, True])
+@pytest.mark.parametrize("opts", [dict(), dict(emit_mode=2), dict(lanes=2)])
+def test_counts_produced_on_the_cohorts_own_stream(cohort_data, opts, given):
+    """ready_stream = ed_cohort_stream() (lane 0's emission stream, which the header invites callers to produce on) with slabs in flight: the fit
+    stream -- the fit, or for given parameters the constants / table statistics / table build -- reads the counts too and must be ordered behind
+    the producer (the event was skipped when ready_stream was the emission stream itself).  The producer is made slow on purpose:
+    a spin kernel, then the copy that fills the slab's buffers (zeros until then)."""
+    torch = pytest.importorskip("torch")
+    edlib, plan, slabs, want, S = cohort_data
+    em = opts.get("emit_mode", 0)
+    if em:
+        key = "want_mode_%d" % em
+        if key not in _CACHE:
+            _CACHE[key] = _reference_results(edlib, plan, slabs, em)
+        want = _CACHE[key]
+    dev = torch.device("cuda", 0)
+    co = edlib.Cohort(plan, S, 4, **opts)
+    ext = torch.cuda.ExternalStream(co.stream, device=dev)
+    src = [(torch.from_numpy(t).to(dev), torch.from_numpy(r).to(dev)) for t, r in slabs[:4]]
+    par = [(torch.from_numpy(w["phi"]).to(dev), torch.from_numpy(w["expected"]).to(dev)) for w in want[:4]]
+    torch.cuda.synchronize()
+    tickets, keep = [], []
+    for rnd in range(2):
+        for i in range(4):
+            dt, dr = torch.zeros_like(src[i][0]), torch.zeros_like(src[i][1])
+            dp, de = torch.zeros_like(par[i][0]), torch.zeros_like(par[i][1])
+            keep.append((dt, dr, dp, de))
+            if len(tickets) >= 4:
+                j = len(tickets) - 4
+                got = co.results(tickets[j], S, path=True)
+                _same(got, want[j % 4], ("calls", "path") if given else ("calls", "path", "phi", "expected"))
+            with torch.cuda.stream(ext):
+                torch.cuda._sleep(20_000_000)                      # ~10 ms: the counts are NOT there when the submission returns
+                dt.copy_(src[i][0]); dr.copy_(src[i][1]); dp.copy_(par[i][0]); de.copy_(par[i][1])
+            tickets.append(co.submit(dt, dr, phi=dp if given else None, expected=de if given else None, ready_stream=co.stream))
+    for j in range(4, 8):
+        got = co.results(tickets[j], S, path=True)
+        _same(got, want[j % 4], ("calls", "path") if given else ("calls", "path", "phi", "expected"))
+    co.close()
+
+
 def test_given_parameters_and_mixture(cohort_data, oracle):
     edlib, plan, slabs, want, S = cohort_data
     test, ref = slabs[1]

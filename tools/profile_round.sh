@@ -83,6 +83,26 @@ for s_, e_ in iv[1:]:
     else:
         cur_e = max(cur_e, e_)
 union += cur_e - cur_s
+# per kernel over the TIMED steps only (from the first timed emission launch on): launches, mean own duration, union of the intervals per launch --
+# the set-up and warm-up launches (which run nearly alone) are not in these averages.  bench.py's roofline.frac = bytes per launch / union_ms_per_launch
+# of the emission kernel / 8 TB/s; its kernel_ms_own = mean_ms.
+t_begin = iv[0][0]
+per = {}
+for r in csv.DictReader(open(sys.argv[1] + "/ks_kernel_trace.csv")):
+    a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if a < t_begin or "(anonymous namespace)::" not in r["Kernel_Name"]:
+        continue
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+    per.setdefault(name, []).append((a, b))
+with open(sys.argv[1] + "/kernel_stats_timed.csv", "w", newline="") as f:
+    w = csv.writer(f); w.writerow(["kernel", "launches", "mean_ms", "union_ms_per_launch", "launches_in_flight_while_any", "total_ms"])
+    for name, lst in sorted(per.items(), key=lambda kv: -sum(b - a for a, b in kv[1])):
+        lst.sort(); u = 0; cs, ce = lst[0]
+        for a, b in lst[1:]:
+            if a > ce: u += ce - cs; cs, ce = a, b
+            else: ce = max(ce, b)
+        u += ce - cs; tot = sum(b - a for a, b in lst)
+        w.writerow([name, len(lst), "%.4f" % (tot / len(lst) / 1e6), "%.4f" % (u / len(lst) / 1e6), "%.3f" % (tot / u), "%.3f" % (tot / 1e6)])
 overlap = {"launches": len(iv), "mean_ms_per_launch": sum(e_ - s_ for s_, e_ in iv) / len(iv) / 1e6, "union_ms_per_launch": union / len(iv) / 1e6,
            "launches_in_flight_while_any": sum(e_ - s_ for s_, e_ in iv) / union, "span_ms_per_launch": (iv[-1][1] - iv[0][0]) / len(iv) / 1e6}
 json.dump({"tag": sys.argv[2], "csrc_sha16": _build.csrc_sha16(), "pmc_steps": 3, "kernel_stats_steps": 6, "emission_overlap": overlap,
