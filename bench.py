@@ -677,7 +677,7 @@ def multi_device_main(args):
     for i in range(N):                              # every device's share: the same synthetic slab (weak scaling)
         pt.array[i * S:(i + 1) * S] = th; pr.array[i * S:(i + 1) * S] = rh
     opts = {"emit_mode": 2, "counts_layout": 1} if args.emit_mode == "tables" else {}
-    slab = min(S, 512)                              # two slabs per device and step: upload of the second under the compute of the first
+    slab = min(S, 256)                              # four slabs per device and step from the shared queue: upload of the next under the compute of the last
     m = ed.MultiDevice(chrom_off, start, end, slab, devices=devices, **opts)
     par = {} if args.fit else {"phi": np.tile(phi.cpu().numpy(), N), "expected": np.tile(p.cpu().numpy(), N)}
     for _ in range(max(1, args.warmup)):
@@ -687,18 +687,20 @@ def multi_device_main(args):
         res = m.run_host(pt.array, pr.array, 1, **par)
     el = time.perf_counter() - t0
     n_calls = len(res["calls"])
-    per_dev = [int(np.sum((res["calls"]["sample"] >= b) & (res["calls"]["sample"] < e))) for _, b, e, _ in res["shares"]]
+
     out = {"metric": "exons*samples/s through betabinom emissions + Viterbi" + (" + dispersion fit" if args.fit else ""),
            "value": float(E) * S * N * args.steps / el, "unit": "exons*samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[2] geometry per device: %d exons x %d samples, %d chromosomes, phi %s; ONE process, %d device(s) %s, "
                                   "host-resident counts (pinned, uint16 on the link, [samples][exons]) -> ed_multi_run_host -> merged call table"
                                   % (E, S, C, "fitted on device" if args.fit else "given", N, devices),
-                      "exons": E, "samples_per_gpu": S, "samples_total": S * N, "fit": bool(args.fit), "emit_mode": args.emit_mode, "driver": "multi-device (ed_multi_run_host: one host thread per device, no collective)",
+                      "exons": E, "samples_per_gpu": S, "samples_total": S * N, "fit": bool(args.fit), "emit_mode": args.emit_mode, "driver": "multi-device (ed_multi_run_host: one host thread per device, slabs from one queue, no collective)",
                       "slab_samples": slab, "devices": devices},
            "includes_h2d": True, "bytes_on_the_link_per_step": 2.0 * 2 * E * S * N,
-           "shares": [{"device": d, "columns": [b, e], "thread_seconds_last_step": sec} for d, b, e, sec in res["shares"]],
-           "n_calls": n_calls, "n_calls_per_device": per_dev, "table_stats": res["table_stats"], "n_unconverged": res["n_unconverged"],
+           "devices": res["devices"],
+           "devices_note": "last step: slabs / columns every device took from the shared queue, wall seconds of its host thread, the NUMA node the thread was kept on "
+                           "(-1 unknown): an uneven split on an otherwise idle node points at a slow device or link",
+           "n_calls": n_calls, "table_stats": res["table_stats"], "n_unconverged": res["n_unconverged"],
            "note": "host-fed: comparable with h2d.pinned of the default line (N = 1), not with its device-resident value; no roofline / cpu_baseline "
                    "on this line (see the default line)"}
     print(json.dumps(out))

@@ -133,7 +133,7 @@ SYMBOLS = [
     ("ed_multi_run_status", C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     ("ed_multi_table_status", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_multi_copy_bins", C.c_int, [_vp, _vp, _vp]),
-    ("ed_multi_shares", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("ed_multi_device_stats", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("ed_fit_betabin_host", C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("ed_select_reference_set_host", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.POINTER(_i32), C.POINTER(_i64)]),
     ("ed_batch_set_fit_mode", C.c_int, [_vp, C.c_int]),

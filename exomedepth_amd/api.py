@@ -73,6 +73,11 @@ def get_loglike_matrix(phi, expected, total, observed, mixture=1.0, return_error
     return (out.T, nerr.value) if return_errors else out.T
 
 
+def device_count():
+    """HIP devices visible to the process (ed_device_count)"""
+    return int(lib().ed_device_count())
+
+
 def viterbi_hmm(transitions, loglikelihood, positions, expected_CNV_length):
     """reference R/tools.R:88-103.  loglikelihood: (nobs, nstates) in HMM order (normal, deletion,
     duplication).  Returns {'Viterbi.path': int array, 'calls': structured array with fields
@@ -773,7 +778,7 @@ class Cohort:
 
 class MultiDevice:
     """ed_cohort_run_host over several devices from ONE process (ed_multi_*; csrc/edmulti.inc): the exon design replicated per
-    device, contiguous shares of whole slabs, one host thread per device, call tables concatenated in column order.
+    device, the slabs dealt from one queue, one host thread per device, call tables put together in column order.
     devices=None: every visible device once; a device may be listed more than once."""
 
     def __init__(self, chrom_off, start, end, slab_samples, devices=None, slabs_in_flight=2, transition_probability=1e-4,
@@ -812,7 +817,7 @@ class MultiDevice:
             pass
 
     def run_host(self, test, ref, layout, phi=None, expected=None, mixture=1.0, want_path=False):
-        """as Cohort.run_host; the result also carries `shares`: [(device, first column, end column, seconds of its thread)]"""
+        """as Cohort.run_host; the result also carries `devices`: per device the slabs / columns it took from the queue, its thread's seconds, its NUMA node"""
         test, ref = np.ascontiguousarray(test), np.ascontiguousarray(ref)
         if test.dtype != ref.dtype or test.dtype not in (np.dtype(np.int32), np.dtype(np.uint16)):
             raise ValueError("test and ref must both be int32 or both uint16")
@@ -842,9 +847,9 @@ class MultiDevice:
         if want_path:
             out["path"] = path
         D = self.n_devices
-        dv, b, e, sec = (C.c_int * D)(), (C.c_int64 * D)(), (C.c_int64 * D)(), (C.c_double * D)()
-        check(lib().ed_multi_shares(self.handle, dv, b, e, sec))
-        out["shares"] = [(int(dv[i]), int(b[i]), int(e[i]), float(sec[i])) for i in range(D)]
+        dv, ns, nc, sec, nn = (C.c_int * D)(), (C.c_int64 * D)(), (C.c_int64 * D)(), (C.c_double * D)(), (C.c_int * D)()
+        check(lib().ed_multi_device_stats(self.handle, dv, ns, nc, sec, nn))
+        out["devices"] = [{"device": int(dv[i]), "slabs": int(ns[i]), "columns": int(nc[i]), "seconds": float(sec[i]), "numa_node": int(nn[i])} for i in range(D)]
         return out
 
 

@@ -22,7 +22,12 @@
 // the arithmetic must match the CPU checker bit for bit).
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>

@@ -592,15 +592,19 @@ int ed_cohort_copy_bins(ed_cohort* cohort, double* phi_bins_out, double* edges_o
 /* ---- one process, several devices --------------------------------------------------------------------------------------
  * ed_cohort_run_host over every device of the node.  The reference's user loops over the samples of a cohort in one R process
  * (vignette/vignette.Rnw:390-431) and the samples are independent (R/class_definition.R:82-191, :311-419 see one test vector each), so
- * nothing is exchanged on the path: the plan is replicated on every device, the cohort's columns are cut into one contiguous share of
- * whole slabs per device, one host thread per device drives an ordinary cohort pipeline over its share (reading the caller's host
- * matrices in place, writing its windows of the outputs), and the compact call tables are concatenated in device order = column
- * order.  Results are those of ed_cohort_run_host on one device, bit for bit.
+ * nothing is exchanged on the path: the plan is replicated on every device, the cohort's slabs sit in ONE queue, one host thread per
+ * device drives an ordinary cohort pipeline over the slabs it takes from it (reading the caller's host matrices in place, writing its
+ * windows of the outputs) -- a slower or busier device takes fewer slabs instead of setting the wall time with a fixed share -- and the
+ * compact call tables are put together in slab order = column order.  Every slab is fitted and called on its own, so the results are those
+ * of ed_cohort_run_host with the same slab_samples on one device, bit for bit, whatever the number of devices and whichever device served
+ * a slab.  A device's thread is kept on the CPUs of the device's NUMA node when sysfs names one (option "numa_bind", default 1; never the
+ * caller's own thread).
  *   devices / n_devices   HIP device ordinals; NULL / 0 = every visible device once.  A device may be named more than once
  *                         (two pipelines on one GPU: how a single-GPU box exercises the threads and the merge)
  *   the plan arguments as ed_plan_create, slab_samples / slabs_in_flight as ed_cohort_create, options as ed_cohort_set_option
  * ed_multi_run_host / _copy_calls / _run_status / _table_status / _copy_bins: as their ed_cohort_* namesakes, over all devices.
- * ed_multi_shares: columns [begin[i], end[i]) device i took in the last run and the wall seconds of its thread. */
+ * ed_multi_device_stats: slabs and columns device i took from the queue in the last run, the wall seconds of its thread and the NUMA node
+ * it was kept on (-1: unknown); arrays of ed_multi_n_devices entries, any may be NULL. */
 typedef struct ed_multi ed_multi;
 int ed_multi_create(ed_multi** multi, const int* devices, int n_devices, int64_t n_exons, int32_t n_chrom, const int32_t* chrom_off,
                     const int32_t* start, const int32_t* end, double transition_probability, double expected_cnv_length,
@@ -614,7 +618,7 @@ int ed_multi_copy_calls(ed_multi* multi, ed_call* calls, ed_call_info* info, int
 int ed_multi_run_status(ed_multi* multi, int64_t* n_unconverged, int64_t* n_gsl_errors);
 int ed_multi_table_status(ed_multi* multi, int64_t out[4]);
 int ed_multi_copy_bins(ed_multi* multi, double* phi_bins_out, double* edges_out);
-int ed_multi_shares(ed_multi* multi, int* devices, int64_t* begin, int64_t* end, double* seconds);
+int ed_multi_device_stats(ed_multi* multi, int* devices, int64_t* n_slabs, int64_t* n_columns, double* seconds, int* numa_nodes);
 
 /* The model fit of new('ExomeDepth') alone, for every column of a host-resident cohort: what stands where the reference calls
  * aod::betabin(cbind(test, reference) ~ 1, random = ~ 1) and fitted(mod) (R/class_definition.R:118-119, :168).  layout / wire as

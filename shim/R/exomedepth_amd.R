@@ -12,11 +12,13 @@
 ##   counts      integer matrix, exons x samples (columns named by sample), rows in any order
 ##   emit.mode   0: GSL's arithmetic operation for operation; 2 (default): table-driven emissions, sample-major -- R's
 ##               column-major matrix is uploaded as it lies (include/exomedepth_amd.h: ed_batch_set_emit_mode)
-##   devices     NULL (default): every GPU of the node -- the samples are independent, so the columns are dealt to the
-##               devices as contiguous shares, one host thread per device inside the .Call (ed_multi_*); or an integer
-##               vector of device ordinals (0-based)
+##   devices     NULL (default): every GPU of the node -- the samples are independent, so the slabs are dealt to the
+##               devices from one queue, one host thread per device inside the .Call (ed_multi_*); or an integer
+##               vector of device ordinals (0-based).  The result does not depend on it
+##   slab        samples per slab of the pipeline (the unit the devices take from the queue and the fit's histograms are
+##               laid out for): results are reproducible for a given slab whatever the node
 CallCNVs.cohort <- function(counts, chromosome, start, end, name, transition.probability = 1e-4, expected.CNV.length = 50000,
-                            n.bins.reduced = 10000, fit.mode = 0L, phi.bins = 1L, emit.mode = 2L, devices = NULL) {
+                            n.bins.reduced = 10000, fit.mode = 0L, phi.bins = 1L, emit.mode = 2L, devices = NULL, slab = 256L) {
   if (length(start) != length(chromosome) || length(end) != length(chromosome) || length(name) != length(chromosome))
     stop('Chromosome, name, start and end vector must have the same lengths.\n')          # R/class_definition.R:319
   if (nrow(counts) != length(chromosome)) stop('The annotation vectors must have the same length as the rows of counts')
@@ -35,7 +37,7 @@ CallCNVs.cohort <- function(counts, chromosome, start, end, name, transition.pro
               PACKAGE = "ExomeDepth")
   ## new('ExomeDepth') + CallCNVs() for every sample
   r <- .Call("ed_call_cnvs_batch", counts, rs$reference, chrom.off, as.integer(start), as.integer(end),
-             as.double(transition.probability), as.double(expected.CNV.length), NULL, NULL, 1.0, 1024L, 0L,
+             as.double(transition.probability), as.double(expected.CNV.length), NULL, NULL, 1.0, as.integer(slab), 0L,
              as.integer(fit.mode), as.integer(phi.bins), as.integer(emit.mode),
              if (is.null(devices)) NULL else as.integer(devices), PACKAGE = "ExomeDepth")
   calls <- data.frame(sample = colnames(counts)[r$sample], start.p = r$start.p, end.p = r$end.p,

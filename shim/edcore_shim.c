@@ -118,9 +118,9 @@ static void edr_guard_release(SEXP p)
  *   phi_bins          the reference's phi.bins (R/class_definition.R:86, :120-147): 1 = one dispersion per sample; 2..8 = one per depth
  *                     level of the reference counts, phi.linear interpolated per exon (phi / expected cannot be given then)
  *   devices           integer vector of HIP device ordinals, or NULL = every visible device: the samples are independent
- *                     (vignette/vignette.Rnw:390-431 loops over them), so the cohort's columns are dealt to the devices as contiguous
- *                     shares of whole slabs, one host thread per device (include/exomedepth_amd.h: ed_multi_*); R objects are touched
- *                     by the calling thread only -- the worker threads see plain C arrays
+ *                     (vignette/vignette.Rnw:390-431 loops over them), so the cohort's slabs are dealt to the devices from one queue,
+ *                     one host thread per device (include/exomedepth_amd.h: ed_multi_*); R objects are touched by the calling thread
+ *                     only -- the worker threads see plain C arrays.  The result does not depend on the number of devices
  * Value: list(sample, start.p, end.p, type, nexons, BF, reads.expected, reads.observed, reads.ratio  -- one element per call,
  *             ordered by (sample, chromosome, position); sample / start.p / end.p 1-based, type 1 = deletion 2 = duplication --
  *             phi, expected (double[n_samples]), path (raw matrix or NULL), n.unconverged, n.gsl.errors,
@@ -152,12 +152,11 @@ SEXP edr_call_cnvs_batch(SEXP test, SEXP reference, SEXP chrom_off, SEXP start, 
   R_SetExternalPtrAddr(guard, gd);
   R_RegisterCFinalizerEx(guard, edr_guard_release, TRUE);
   const int n_dev = devices == R_NilValue ? 0 : (int)XLENGTH(devices);
+  /* The slab width is the caller's, whatever the number of devices: the devices take whole slabs from one queue, every slab is fitted and called on its
+   * own, and so the result does not depend on how many GPUs the node happens to show (the width used to shrink to ceil(S / devices), and with
+   * it the slab composition the fit's histogram geometry is chosen from).  A cohort of fewer slabs than devices leaves devices idle. */
   int sl = INTEGER(slab)[0];
   if (sl <= 0 || sl > S) sl = S;
-  {                       /* every device gets a share: no slab wider than the cohort's width over the devices */
-    const int nd = n_dev > 0 ? n_dev : ed_device_count();
-    if (nd > 1 && sl > (S + nd - 1) / nd) sl = (S + nd - 1) / nd;
-  }
   int rc = ed_multi_create(&gd->multi, n_dev > 0 ? INTEGER(devices) : NULL, n_dev, E, C, INTEGER(chrom_off), INTEGER(start), INTEGER(end),
                            REAL(tprob)[0], REAL(ecl)[0], sl, 2);
   if (rc != ED_OK) {

@@ -206,6 +206,79 @@ def test_whole_cohort_from_host_memory(cohort_data, layout, wire, pinned):
     del keep
 
 
+@pytest.mark.parametrize("kind", ["int32 pageable", "uint16 pageable", "int32 pinned", "uint16 pinned", "int32 pageable, narrowing off"])
+def test_host_fed_slabs_stay_16_bits_wide_in_the_sample_major_table_mode(cohort_data, kind):
+    """What the R-level entry runs (shim/edcore_shim.c: emit mode 2, R's column-major matrices, wire = 4): int32 blocks in pageable memory are
+    narrowed to uint16 by the host threads that stage them and the slab stays uint16 on the device; uint16 blocks go up as they lie; int32 in
+    pinned memory is read in place and stays int32.  The results are the device-resident int32 run's, bit for bit, either way -- and a slab with
+    ONE count beyond 65 535 in its middle goes up 32 bits wide (the others still 16)."""
+    edlib, plan, slabs, want, S = cohort_data
+    if "want_mode_2" not in _CACHE:
+        _CACHE["want_mode_2"] = _reference_results(edlib, plan, slabs, 2)
+    want = _CACHE["want_mode_2"]
+    test = np.concatenate([t for t, _ in slabs], axis=1)
+    ref = np.concatenate([r for _, r in slabs], axis=1)
+    St = test.shape[1]
+    dt = np.uint16 if kind.startswith("uint16") else np.int32
+    th, rh = np.ascontiguousarray(test.T.astype(dt)), np.ascontiguousarray(ref.T.astype(dt))
+    keep = []
+    if "pinned" in kind:
+        pt, pr = edlib.PinnedArray(th.shape, dt), edlib.PinnedArray(rh.shape, dt)
+        pt.array[...] = th; pr.array[...] = rh
+        th, rh = pt.array, pr.array
+        keep = [pt, pr]
+    opts = dict(emit_mode=2, counts_layout=1)
+    if kind.endswith("off"):
+        opts["host_narrow"] = 0
+    co = edlib.Cohort(plan, S, 2, **opts)
+    calls = np.concatenate([w["calls"] for w in want])
+    calls["sample"] += np.concatenate([np.full(len(w["calls"]), k * S, dtype=np.int32) for k, w in enumerate(want)])
+    path = np.concatenate([w["path"] for w in want], axis=1)
+    for rep in range(2):
+        out = co.run_host(th, rh, 1, want_path=True)
+        assert out["calls"].tobytes() == calls.tobytes()
+        assert np.array_equal(out["path"].T, path)
+        # (fitted from [samples][exons] counts here, from [exons][samples] in `want`: the same optimum to the fit's tolerance, so the decoration agrees
+        #  to that and not to the bit; with GIVEN parameters -- below -- everything is bit for bit)
+        assert np.allclose(out["phi"], np.concatenate([w["phi"] for w in want]), rtol=1e-8, atol=0)
+        winfo = np.concatenate([w["info"] for w in want])
+        for f in winfo.dtype.names:
+            a, bq = out["info"][f], winfo[f]
+            assert np.array_equal(a, bq) if a.dtype.kind in "iu" else np.allclose(a, bq, rtol=1e-6, atol=0), f
+        if rep == 0:
+            first = {k: np.array(out[k], copy=True) for k in ("calls", "info", "path", "phi", "expected")}
+        else:                                                   # the same run twice: bit for bit
+            assert all(first[k].tobytes() == np.asarray(out[k]).tobytes() for k in first)
+    nbytes, _ = co.ingest_stats()
+    narrowed = kind in ("int32 pageable", "uint16 pageable", "uint16 pinned")
+    assert nbytes == 2 * 2 * plan.n_exons * St * (2 if narrowed else 4)
+    assert co.n_wide_slabs() == 0
+    co.close()
+    if kind == "int32 pageable":
+        # given parameters, and a count that does not fit 16 bits in the middle of the second slab
+        rng = np.random.default_rng(8)
+        phi = rng.uniform(0.002, 0.02, St); p = rng.uniform(0.08, 0.2, St)
+        big_t, big_r = test.copy(), ref.copy()
+        big_r[plan.n_exons // 2, S + S // 2] = 70_000
+        big_t[7, S + 3] = 65_536
+        b = edlib.Batch(plan, St)
+        b.set_emit_mode(2)
+        b.run(big_t, big_r, phi, p)
+        co = edlib.Cohort(plan, S, 2, **opts)
+        out = co.run_host(np.ascontiguousarray(big_t.T), np.ascontiguousarray(big_r.T), 1, phi=phi, expected=p, want_path=True)
+        assert out["calls"].tobytes() == b.calls().tobytes() and out["info"].tobytes() == b.call_info().tobytes()
+        assert np.array_equal(out["path"].T, b.path())
+        assert co.n_wide_slabs() == 1
+        # ... and a negative count (invalid input, the strict arithmetic's business): wide as well, same result as the int32 path
+        neg = test.copy(); neg[11, 5] = -3
+        b2 = edlib.Batch(plan, St); b2.set_emit_mode(2); b2.run(neg, ref, phi, p)
+        out = co.run_host(np.ascontiguousarray(neg.T), np.ascontiguousarray(ref.T), 1, phi=phi, expected=p, want_path=True)
+        assert out["calls"].tobytes() == b2.calls().tobytes() and np.array_equal(out["path"].T, b2.path())
+        assert co.n_wide_slabs() == 2
+        b.close(); b2.close(); co.close()
+    del keep
+
+
 def test_stage_ms_reports_the_last_fit_and_run_after_folding(cohort_data):
     """after the canonical fit -> run sequence ed_batch_stage_ms must report both, also after ed_batch_stage_ms_total"""
     edlib, plan, slabs, want, S = cohort_data

@@ -1,5 +1,5 @@
-"""One process, several devices (ed_multi_*; csrc/edmulti.inc): the cohort's columns dealt to the devices as contiguous shares of whole
-slabs, one host thread per device, call tables merged in column order.  The samples are independent on this path (reference
+"""One process, several devices (ed_multi_*; csrc/edmulti.inc): the cohort's slabs dealt to the devices from one queue,
+one host thread per device, call tables merged in column order.  The samples are independent on this path (reference
 vignette/vignette.Rnw:390-431 loops over them; R/class_definition.R:82-191, :311-419 see one test vector each), so the merged result
 must be the single-device result bit for bit.  The GPU box has one device: it is named several times (two / three pipelines on one
 GPU), which exercises the threads, the shares and the merge; on a node `devices=None` takes every visible GPU."""
@@ -19,9 +19,9 @@ def _case(E=8000, S=230, seed=77):
 
 
 def _same(a, b):
-    assert set(a) - {"shares"} == set(b) - {"shares"}
+    assert set(a) - {"devices"} == set(b) - {"devices"}
     for k in a:
-        if k in ("shares",):
+        if k in ("devices",):
             continue
         if isinstance(a[k], dict) or isinstance(a[k], int):
             assert a[k] == b[k], k
@@ -47,11 +47,29 @@ def test_several_pipelines_give_the_single_device_result(edlib, opts, layout):
         D = m.n_devices
         m.close()
         _same(want, got); _same(want, again)
-        sh = got["shares"]
-        assert len(sh) == D and sh[0][1] == 0 and sh[-1][2] == S
-        assert all(sh[i][2] == sh[i + 1][1] for i in range(D - 1)) and all(b % slab == 0 for _, b, _, _ in sh)
-        if devs is not None and len(devs) > 1:
-            assert all(e > b for _, b, e, _ in sh)     # 5 slabs over 2 / 3 pipelines: everybody works
+        dv = got["devices"]
+        assert len(dv) == D and sum(d["slabs"] for d in dv) == 5 and sum(d["columns"] for d in dv) == S
+        assert all(d["seconds"] > 0 for d in dv)
+
+
+def test_a_throttled_pipeline_takes_fewer_slabs(edlib):
+    """the queue at work: two pipelines on the one GPU, many small slabs -- whatever the split, the merged table is the single-device one; and with a
+    pipeline that can hold one slab against one that holds four, both still finish the cohort between them"""
+    chrom_off, start, end, test, ref, p, phi = _case(E=4000, S=600, seed=80)
+    slab = 20                                       # 30 slabs
+    opts = {"emit_mode": 2, "counts_layout": 1}
+    t_in, r_in = np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)
+    plan = ed.Plan(chrom_off, start, end)
+    co = ed.Cohort(plan, slab, 2, **opts)
+    want = co.run_host(t_in, r_in, 1, want_path=True)
+    co.close(); plan.close()
+    for devs, inflight in (([0, 0], 1), ([0, 0, 0], 4), ([0] * 8, 2)):
+        m = ed.MultiDevice(chrom_off, start, end, slab, devices=devs, slabs_in_flight=inflight, **opts)
+        for rep in range(3):
+            got = m.run_host(t_in, r_in, 1, want_path=True)
+            _same(want, got)
+            assert sum(d["slabs"] for d in got["devices"]) == 30 and sum(d["columns"] for d in got["devices"]) == 600
+        m.close()
 
 
 def test_given_parameters_and_uint16_wire(edlib):
@@ -70,8 +88,11 @@ def test_given_parameters_and_uint16_wire(edlib):
 
 def test_errors_name_the_device_and_more_devices_than_slabs(edlib):
     chrom_off, start, end, test, ref, p, phi = _case(E=3000, S=40, seed=79)
-    with pytest.raises(ed.EdError, match="device 7"):
-        ed.MultiDevice(chrom_off, start, end, 40, devices=[0, 7])
+    bad = ed.device_count()                         # (always one past the last visible device, on an 8-GPU node too)
+    with pytest.raises(ed.EdError, match="device %d of %d visible" % (bad, bad)):
+        ed.MultiDevice(chrom_off, start, end, 40, devices=[0, bad])
+    with pytest.raises(ed.EdError, match="device -1"):
+        ed.MultiDevice(chrom_off, start, end, 40, devices=[-1])
     # one slab, three pipelines: two of them get nothing to do
     plan = ed.Plan(chrom_off, start, end)
     co = ed.Cohort(plan, 40, 2)
@@ -79,7 +100,7 @@ def test_errors_name_the_device_and_more_devices_than_slabs(edlib):
     co.close(); plan.close()
     m = ed.MultiDevice(chrom_off, start, end, 40, devices=[0, 0, 0])
     got = m.run_host(test, ref, 0)
-    assert sum(1 for _, b, e, _ in got["shares"] if e > b) == 1
+    assert sum(1 for d in got["devices"] if d["slabs"] > 0) == 1
     _same(want, got)
     # a failing share (phi given for some, NaN-free but phi_bins > 1 refuses given parameters): the caller gets the device's message
     m.close()
