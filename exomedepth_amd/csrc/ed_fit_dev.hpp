@@ -110,4 +110,52 @@ __device__ __forceinline__ void accumulate_cell(Acc& acc, double a, double b, do
   acc.hbb += q2 - q3;
 }
 
+// psi / psi' without the logarithm for an argument known to be >= 32: four Bernoulli terms (the fifth is below 7e-18 there)
+__device__ __forceinline__ void digamma_trigamma_nolog_big(double x, double& psi_rest, double& psi1)
+{
+  const double r = frcp(x);
+  const double w = r * r;
+  double p = -1.0 / 240.0;                     // B8/8
+  p = ed_pm_fma_k(p, w, 1.0 / 252.0);        // B6/6
+  p = ed_pm_fma_k(p, w, -1.0 / 120.0);       // B4/4
+  p = ed_pm_fma_k(p, w, 1.0 / 12.0);         // B2/2
+  psi_rest = -0.5 * r - p * w;
+  double q = -1.0 / 30.0;                      // B8
+  q = ed_pm_fma_k(q, w, 1.0 / 42.0);         // B6
+  q = ed_pm_fma_k(q, w, -1.0 / 30.0);        // B4
+  q = ed_pm_fma_k(q, w, 1.0 / 6.0);          // B2
+  psi1 = __builtin_fma(q * w, r, __builtin_fma(0.5, w, r));
+}
+
+// accumulate_cell for a run of cells (k_fit_accum).  The gradient needs sum_e ln(x1 / x3) and sum_e ln(x2 / x3): the ratios of a run are MULTIPLIED
+// (pa, pb) and the caller takes one logarithm per run of eight cells instead of two per cell -- ln of a product of eight factors carries the same
+// ~1e-15 of absolute error as the sum of eight rounded logarithms, and the factors (>= 10 / 2^31 each: the arguments come back shifted to >= 10)
+// cannot leave the range.  `big`: wave-uniform, every lane's three arguments are >= 32 (the short series).
+// (Round 6 also built the test-count terms from per-test histograms shared by the K prefixes of the cohort reference sets -- one reciprocal per distinct
+// count instead of a digamma + trigamma evaluation per cell, review r5 item 2 -- and measured nothing: 13.95 against 13.95 ms for the stage, same box,
+// alternating.  After the two changes above the stage is no longer bound by this kernel (4.6 of its 14 ms); the form is not in the tree.)
+__device__ __forceinline__ void accumulate_cell_run(Acc& acc, double& pa, double& pb, double a, double b, double th, int y, int n, bool big)
+{
+  if (n <= 0) return;
+  double x1, r1, q1, x2, r2, q2, x3, r3, q3;
+  if (big) {
+    x1 = a + (double)y; x2 = b + (double)(n - y); x3 = th + (double)n;
+    digamma_trigamma_nolog_big(x1, r1, q1);
+    digamma_trigamma_nolog_big(x2, r2, q2);
+    digamma_trigamma_nolog_big(x3, r3, q3);
+  } else {
+    digamma_trigamma_nolog(a + (double)y, x1, r1, q1);
+    digamma_trigamma_nolog(b + (double)(n - y), x2, r2, q2);
+    digamma_trigamma_nolog(th + (double)n, x3, r3, q3);
+  }
+  const double i3 = frcp(x3);
+  pa *= x1 * i3;
+  pb *= x2 * i3;
+  acc.ga += r1 - r3;
+  acc.gb += r2 - r3;
+  acc.haa += q1 - q3;
+  acc.hab -= q3;
+  acc.hbb += q2 - q3;
+}
+
 }  // namespace edfit

@@ -1,5 +1,6 @@
-"""The N>1 path on CPU: two ranks over the gloo backend gather their call tables exactly as the RCCL
-path does on GPUs (same code, exomedepth_amd/dist.py)."""
+"""The N>1 path on CPU: 2, 3 (ragged shards) and 8 ranks over the gloo backend gather their call tables, merge the sharded
+select.reference.set and exchange the cohort's count slabs exactly as the RCCL path does on GPUs (same code,
+exomedepth_amd/dist.py): the rank-offset arithmetic, shards of unequal width, ranks that own nothing."""
 import os
 import socket
 
@@ -19,12 +20,25 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _spawn(world, target, args, n_results):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(n_results)]
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    return got
+
+
+def _worker(rank, world, port, q, S_total):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from exomedepth_amd import api, dist as eddist
-    S_total = 10
     lo, hi = eddist.shard_bounds(S_total, rank, world)
     # each rank fabricates the call table its shard would produce: sample s has (s % 3) calls
     rows = []
@@ -42,22 +56,23 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gather_call_tables_world_size_2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=120)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+@pytest.mark.parametrize("world,S_total", [(2, 10), (3, 10), (8, 21), (8, 5)])     # (8, 5): three ranks own no sample at all
+def test_gather_call_tables(world, S_total):
+    got = _spawn(world, _worker, (S_total,), 1)[0]
     exp = []
-    for s in range(10):
+    for s in range(S_total):
         for k in range(s % 3):
             exp.append((s, k % 2, 100 * s + k, 100 * s + k + 4, 1 + (k % 2), 5))
     assert got.tolist() == [list(r) for r in exp]     # ordered by global sample, sample ids shifted per rank
+
+
+def test_shard_bounds_tile_the_axis():
+    from exomedepth_amd import dist as eddist
+    for n in (0, 1, 5, 8, 13, 1024, 8191):
+        for w in (1, 2, 3, 8):
+            b = [eddist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
 
 
 def _refset_table(R):
@@ -98,19 +113,12 @@ def _refset_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_select_reference_set_sharded_merge_world_size_2():
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_select_reference_set_sharded_merge(world):
     from exomedepth_amd import api
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_refset_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    got = _spawn(world, _refset_worker, (), world)
     exp = api.refset_finalize(_refset_table(31))
+    assert sorted(r for r, _, _ in got) == list(range(world))
     for rank, choice, raw in got:
         assert choice == exp["reference.choice"]
         assert raw == exp["summary.stats"].tobytes()         # every rank ends with the same, complete table
@@ -143,18 +151,10 @@ def _cohort_refsets_worker(rank, world, port, q, S, E):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("S", [12, 13])      # equal shards (one all_gather into the (S, E) buffer) and ragged ones (padded)
-def test_cohort_reference_sets_sharded_gathers_every_column_world_size_2(S):
+# equal shards (one all_gather into the (S, E) buffer), ragged ones (padded to the widest), ranks without a column
+@pytest.mark.parametrize("world,S", [(2, 12), (2, 13), (3, 12), (3, 13), (8, 16), (8, 21), (8, 5)])
+def test_cohort_reference_sets_sharded_gathers_every_column(world, S):
     """the reference-set stage of a sample-sharded cohort (vignette/vignette.Rnw:390-402 needs ALL samples as candidates): every rank
     ends up with the whole (E, S) count matrix, column order intact, and is asked for exactly its own tests"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_cohort_refsets_worker, args=(r, 2, port, q, S, 37)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = sorted(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert got == [(0, True), (1, True)]
+    got = sorted(_spawn(world, _cohort_refsets_worker, (S, 37), world))
+    assert got == [(r, True) for r in range(world)]

@@ -206,6 +206,53 @@ def _fit_both_layouts(edlib, test, ref, by=1):
     return out
 
 
+def test_per_cell_fit_on_ill_conditioned_columns(edlib, oracle):
+    """The per-cell Newton passes (histograms off: the form the reference-set searches run batched) stop when a step over all exons falls below
+    1e-6 (2e-5, kFitStepTol, in the reference-set searches' batched form only -- round 5 had applied it here too), leaving ~C 1e-12 against the
+    fit's 1e-8: pinned here on the columns where C is largest -- tiny dispersions, few exons, low depth, a proportion near 0 or 1 -- against the
+    checker's long-double maximum-likelihood fit."""
+    rng = np.random.default_rng(2026)
+    cases = []
+    for E in (40, 150, 600, 9000):                               # (9000: the coarse passes run too)
+        S = 48
+        phi = np.exp(rng.uniform(np.log(2e-5), np.log(0.3), S))
+        p = np.concatenate([np.exp(rng.uniform(np.log(2e-3), np.log(0.5), S // 2)), 1 - np.exp(rng.uniform(np.log(2e-3), np.log(0.5), S - S // 2))])
+        depth = np.exp(rng.uniform(np.log(15.0), np.log(3000.0), S))
+        n = rng.poisson(depth[None, :] * rng.lognormal(0, 0.6, (E, 1))).astype(np.int64)
+        a, b = p * (1 - phi) / phi, (1 - p) * (1 - phi) / phi
+        q = rng.beta(a[None, :], b[None, :], (E, S))
+        test = rng.binomial(n, q).astype(np.int32)
+        cases.append((test, (n - test).astype(np.int32)))
+    worst = 0.0
+    for test, ref in cases:
+        E, S = test.shape
+        plan = edlib.Plan(np.array([0, E], dtype=np.int32), np.arange(E, dtype=np.int32) * 100, np.arange(E, dtype=np.int32) * 100 + 50)
+        b = edlib.Batch(plan, S)
+        b.set_fit_histograms(0)
+        dphi, dexp = edlib.DeviceArray(np.zeros(S)), edlib.DeviceArray(np.zeros(S))
+        b.fit(test, ref, dphi, dexp)
+        nu, _ = b.fit_unconverged()
+        gphi, gexp = dphi.to_host(), dexp.to_host()
+        b.close(); plan.close()
+        checked = beyond = 0
+        for s in range(S):
+            ophi, op, _, _ = oracle.fit_mle(test[:, s], ref[:, s])
+            if not (2e-6 < ophi < 0.6):                          # (the fit's own bounds on phi: other tests cover the pinned columns)
+                continue
+            # (binary64 gradient sums locate a dispersion below ~1.5e-3 to 2e-14 / phi^2 only -- DESIGN.md 4.5; the checker sums in long double)
+            err = max(abs(gphi[s] - ophi) / ophi, abs(gexp[s] - op) / op) / max(1.0, 2e-6 / (ophi * ophi))
+            checked += 1
+            if err < 1e-8:
+                worst = max(worst, err)
+            else:
+                beyond += 1
+                print("beyond 1e-8: E %d column %d phi %.6g (checker %.6g) expected %.6g (checker %.6g) err %.3g" % (E, s, gphi[s], ophi, gexp[s], op, err))
+        # a column the fit DECLARES converged is within 1e-8; the ones it reports as not converged within its ten passes (40-exon columns whose
+        # likelihood is nearly flat in the dispersion) are the only ones that may lie beyond
+        assert checked >= S // 2 and nu <= S // 6 and beyond <= nu, (E, checked, nu, beyond)
+    assert worst < 1e-8, worst
+
+
 def test_column_pinned_at_the_dispersion_floor_still_converges_its_mean(edlib, oracle):
     """nearly binomial columns (the likelihood's maximum lies below the phi >= 1e-6 the fit allows): phi is pinned at the bound and
     the expected proportion is the maximum GIVEN that phi -- in both layouts, to the fit's tolerance of the checker's"""
