@@ -214,6 +214,8 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
             slabs.append((b, ph, pe))
     th = test[:, cols].cpu().numpy()
     rh = ref[:, cols].cpu().numpy()
+    margins = None
+    max_abs = [0.0]
     for b, ph, pe in slabs:
         calls = b.calls()
         ptr = b.device_pointers()
@@ -233,15 +235,24 @@ def verify_against_oracle(ed, eddist, torch, dev, co, batches, last_ticket, n_ba
                 nz = np.isfinite(ell) & (ell != 0)
                 if nz.any():
                     out["loglik_max_rel_diff"] = max(out["loglik_max_rel_diff"], float(np.max(d[nz] / np.abs(ell[nz]))))
+                    max_abs[0] = max(max_abs[0], float(np.max(d[nz])))
             else:
                 out["loglik_bit_mismatches"] += int(np.sum(got.view(np.int64) != np.ascontiguousarray(ell).view(np.int64)))
             epath, ecalls = eo.callcnvs(ell, chrom_off, start, end)
+            if tables:      # how far the on-path decisions of these columns are from a tie (tools/concordance.py --margins has all 1 024 columns on record)
+                margins = eo.callcnvs_margins(ell, chrom_off, start, end, acc=margins)
             out["discordant_states"] += int(np.sum(path[:, i].astype(np.int8) != epath))
             mine = calls[calls["sample"] == c]
             want = {(int(r[0]) - 1, int(r[1]) - 1, int(r[2]), int(r[3])) for r in ecalls}
             have = {(int(r["start_exon"]), int(r["end_exon"]), int(r["type"]), int(r["nexons"])) for r in mine}
             out["discordant_calls"] += len(want ^ have)
             out["columns"] += 1
+    if margins:
+        out["min_on_path_margin"] = margins["min_margin"]
+        out["on_path_decisions"] = margins["decisions"]
+        out["on_path_margins_below"] = margins["below"]
+        out["on_path_exact_ties"] = margins["ties"]
+        out["loglik_max_abs_diff"] = max_abs[0]
     out["what"] = ("%d columns x %d slab(s) in flight after the timed region: %s, Viterbi "
                    "states and call rows vs the checker's Viterbi, given the (phi, expected) the device used"
                    % (len(cols), len(slabs), "likelihood values vs the checker's LIBM flavour (the reference's arithmetic), 1e-10 RELATIVE with no absolute floor (loglik_needed_abs_floor: values among those beyond it that a 1e-12 floor would have let through)"

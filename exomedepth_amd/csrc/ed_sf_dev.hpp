@@ -369,41 +369,58 @@ __device__ __forceinline__ double psi_n(int n, double x)
   return (n % 2 == 0) ? -v : v;
 }
 
-// lngamma_sgn_sing (src/VP_gamma.c:795-894): x = -N + eps.  Returns the value; *site = 4 on eps == 0 (:803).
+// ---- log|Gamma| next to a pole, x = -N + eps (what gsl reaches at src/VP_gamma.c:795-894) ----------------------------------------------
+// Two expansions in eps, written here as tables + the two polynomial walkers below:
+//   N = 1    Gamma(-1 + eps) eps = -(1 + eps/2 (1 + 3 eps)/(1 - eps^2)) + eps P(eps), P of degree 9 (k_pole1)
+//   N >= 2   log|Gamma| = -[ log N! - eps psi(N+1) + eps^2 psi'(N+1)/2! - ... ] - log( sin(pi eps)/(pi eps) ) - log|eps|:
+//            the bracket is an ALTERNATING Horner sum over c_m = psi^(m-1)(N+1) / (m-1)!, m = 1..7, where the polygamma of order n >= 2 enters
+//            only once |eps| exceeds k_pole_psi_from[n - 2] (below that its term is under the rounding of the sum); the sine ratio is a
+//            degree-5 polynomial in eps^2 (k_pole_sinc).
+// The ORDER of the floating-point operations is the checker's (oracle/edo_gsl.inc), hence the reference's: the fixture
+// tests/golden/sf_ref_negative.npz and test_lnbeta_outside_the_positive_quadrant_matches_the_checker hold it to the bit.
+__constant__ const double k_pole1[10] = {0.07721566490153286061, 0.08815966957356030521, -0.00436125434555340577, 0.01391065882004640689,
+                                         -0.00409427227680839100, 0.00275661310191541584, -0.00124162645565305019, 0.00065267976121802783,
+                                         -0.00032205261682710437, 0.00016229131039545456};
+__constant__ const double k_pole_sinc[6] = {1.0, -1.6449340668482264365, 0.8117424252833536436, -0.1907518241220842137, 0.0261478478176548005,
+                                            -0.0023460810354558236};
+__constant__ const double k_pole_psi_from[5] = {0.00001, 0.0002, 0.001, 0.005, 0.01};      // |eps| above which psi^(2) .. psi^(6) take part
+__constant__ const double k_pole_fact[5] = {6.0, 24.0, 120.0, 720.0, 5040.0};             // 3! .. 7!
+
+// c[0] + x (c[1] + x (... + x c[n-1]))
+__device__ __forceinline__ double poly_up(const double* __restrict__ c, int n, double x)
+{
+  double h = c[n - 1];
+  for (int i = n - 2; i >= 0; --i) h = c[i] + x * h;
+  return h;
+}
+// c[0] - x (c[1] - x (... - x c[n-1]))
+__device__ __forceinline__ double poly_alt(const double* c, int n, double x)
+{
+  double h = c[n - 1];
+  for (int i = n - 2; i >= 0; --i) h = c[i] - x * h;
+  return h;
+}
+
+// Returns the value; *site = 4 on eps == 0 (the pole itself: gsl's domain error at :803).
 __device__ __noinline__ double lngamma_sgn_sing(int N, double eps, double* sgn, unsigned* site)
 {
   if (eps == 0.0) { *sgn = 0.0; *site = 4u; return 0.0; }
+  const double mag = fabs(eps);
   if (N == 1) {
-    const double c0 = 0.07721566490153286061, c1 = 0.08815966957356030521, c2 = -0.00436125434555340577,
-                 c3 = 0.01391065882004640689, c4 = -0.00409427227680839100, c5 = 0.00275661310191541584,
-                 c6 = -0.00124162645565305019, c7 = 0.00065267976121802783, c8 = -0.00032205261682710437,
-                 c9 = 0.00016229131039545456;
-    const double g5 = c5 + eps * (c6 + eps * (c7 + eps * (c8 + eps * c9)));
-    const double g = eps * (c0 + eps * (c1 + eps * (c2 + eps * (c3 + eps * (c4 + eps * g5)))));
-    const double gam_e = (g - 1.0) - ((0.5 * eps) * (1.0 + 3.0 * eps)) / (1.0 - eps * eps);
+    const double tail = eps * poly_up(k_pole1, 10, eps);
+    const double gam_e = (tail - 1.0) - ((0.5 * eps) * (1.0 + 3.0 * eps)) / (1.0 - eps * eps);
     *sgn = (eps > 0.0 ? -1.0 : 1.0);
-    return ed_plog(fabs(gam_e) / fabs(eps));
+    return ed_plog(fabs(gam_e) / mag);
   }
-  const double cs1 = -1.6449340668482264365, cs2 = 0.8117424252833536436, cs3 = -0.1907518241220842137,
-               cs4 = 0.0261478478176548005, cs5 = -0.0023460810354558236;
-  const double e2 = eps * eps;
-  const double sin_ser = 1.0 + e2 * (cs1 + e2 * (cs2 + e2 * (cs3 + e2 * (cs4 + e2 * cs5))));
-  const double aeps = fabs(eps);
-  double psi_2 = 0.0, psi_3 = 0.0, psi_4 = 0.0, psi_5 = 0.0, psi_6 = 0.0;
-  const double c0 = lnfact_u((unsigned)N);
-  const double psi_0 = psi_int(N + 1);
-  const double psi_1 = psi_1_int(N + 1);
-  if (aeps > 0.00001) psi_2 = psi_n(2, N + 1.0);
-  if (aeps > 0.0002) psi_3 = psi_n(3, N + 1.0);
-  if (aeps > 0.001) psi_4 = psi_n(4, N + 1.0);
-  if (aeps > 0.005) psi_5 = psi_n(5, N + 1.0);
-  if (aeps > 0.01) psi_6 = psi_n(6, N + 1.0);
-  const double c1 = psi_0, c2 = psi_1 / 2.0, c3 = psi_2 / 6.0, c4 = psi_3 / 24.0, c5 = psi_4 / 120.0, c6 = psi_5 / 720.0,
-               c7 = psi_6 / 5040.0;
-  const double lng_ser = c0 - eps * (c1 - eps * (c2 - eps * (c3 - eps * (c4 - eps * (c5 - eps * (c6 - eps * c7))))));
-  const double g = -lng_ser - ed_plog(sin_ser);
+  const double sinc = poly_up(k_pole_sinc, 6, eps * eps);
+  double c[8];
+  c[0] = lnfact_u((unsigned)N);
+  c[1] = psi_int(N + 1);
+  c[2] = psi_1_int(N + 1) / 2.0;
+  for (int n = 2; n <= 6; ++n) c[n + 1] = (mag > k_pole_psi_from[n - 2] ? psi_n(n, N + 1.0) : 0.0) / k_pole_fact[n - 2];
+  const double g = -poly_alt(c, 8, eps) - ed_plog(sinc);
   *sgn = ((N & 1) ? -1.0 : 1.0) * (eps > 0.0 ? 1.0 : -1.0);
-  return g - ed_plog(fabs(eps));
+  return g - ed_plog(mag);
 }
 
 // gsl_sf_lngamma_sgn_e (src/VP_gamma.c:1219-1285).  *site: the gsl_error() call the reference makes (0 none,

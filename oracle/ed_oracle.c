@@ -310,6 +310,78 @@ EDO_API long edo_callcnvs(const double *likelihood, long n, const int *chrom_off
   return ncalls;
 }
 
+/* =====================================================================================
+ * Decision margins of the Viterbi path (diagnostic; tools/concordance.py --margins, bench.py's verify).  The forward pass above keeps, per
+ * observation and target state, the FIRST strict maximum of three candidates (reference src/hmm.cpp:78-85); an implementation whose emissions
+ * differ from the reference's in the last bits -- the table-driven emission mode: <= 2e-13 relative -- decodes the same path as long as no
+ * decision ON the decoded path is closer than what those differences can move the candidates.  For every observation i >= 1 and the state the
+ * path is in at i: margin = best candidate - runner-up (0 = an exact tie, resolved by the first-maximum rule on both sides as long as it stays
+ * exact; decisions with a single finite candidate, or forced by a -inf emission (:87), have none).
+ *   likelihood / chrom_off / start / end / transition_probability / expected_cnv_length: as edo_callcnvs
+ *   thresholds[n_thr] ascending; below[t] += on-path decisions with margin < thresholds[t]; *ties += margin == 0; *decisions += decisions with
+ *   two finite candidates; *min_margin = the smallest non-zero margin seen (start it at +inf); *scale_at_min = |best candidate| at that decision
+ * ===================================================================================== */
+EDO_API void edo_callcnvs_margins(const double *likelihood, long n, const int *chrom_off, int nchrom, const int *start, const int *end,
+                                  double transition_probability, double expected_cnv_length, const double *thresholds, int n_thr, long *below,
+                                  long *ties, long *decisions, double *min_margin, double *scale_at_min)
+{
+  const double t = transition_probability;
+  double T[9];
+  const double rows[3][3] = {{1. - t, t / 2., t / 2.}, {0.5, 0.5, 0.}, {0.5, 0., 0.5}};
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) T[c * 3 + r] = rows[r][c];
+  for (int c = 0; c < nchrom; c++) {
+    long lo = chrom_off[c], hi = chrom_off[c + 1], m = hi - lo;
+    if (m <= 0) continue;
+    long nobs = m + 2;
+    unsigned char *from = (unsigned char *)malloc((size_t)nobs * 3);
+    double *marg = (double *)malloc(sizeof(double) * (size_t)nobs * 3);
+    double *mag = (double *)malloc(sizeof(double) * (size_t)nobs * 3);
+    int *tb = (int *)malloc(sizeof(int) * (size_t)nobs);
+    double vit_prev[3] = {0., -HUGE_VAL, -HUGE_VAL}, vit[3], trans[3];
+    int prev_pos = (int)((double)start[lo] - 2 * expected_cnv_length);
+    from[0] = from[1] = from[2] = 0;
+    for (long i = 1; i < nobs; i++) {
+      /* the padded chain of R/class_definition.R:364-368, row by row */
+      int pos = (i <= m) ? start[lo + i - 1] : (int)((double)end[hi - 1] + 2 * expected_cnv_length);
+      double e[3];
+      if (i <= m) { e[0] = likelihood[(lo + i - 1) + n * 1]; e[1] = likelihood[(lo + i - 1) + n * 0]; e[2] = likelihood[(lo + i - 1) + n * 2]; }
+      else { e[0] = 0.; e[1] = -100.; e[2] = -100.; }
+      double dist = (double)pos - (double)prev_pos;
+      double dist_effect = exp(-dist / expected_cnv_length);
+      prev_pos = pos;
+      for (int j = 0; j < 3; j++) {
+        vit[j] = -HUGE_VAL;
+        double second = -HUGE_VAL;
+        int fw = 0;
+        trans[0] = T[j * 3];
+        trans[1] = dist_effect * T[j * 3 + 1] + (1.0 - dist_effect) * T[j * 3];
+        trans[2] = dist_effect * T[j * 3 + 2] + (1.0 - dist_effect) * T[j * 3];
+        for (int k = 0; k < 3; k++) {
+          double newp = e[j] + vit_prev[k] + log(trans[k]);
+          if (newp > vit[j]) { second = vit[j]; vit[j] = newp; fw = k; }
+          else if (newp > second) second = newp;
+        }
+        if (e[j] == -HUGE_VAL) fw = 0;
+        from[i * 3 + j] = (unsigned char)fw;
+        marg[i * 3 + j] = (second > -HUGE_VAL && e[j] > -HUGE_VAL) ? vit[j] - second : HUGE_VAL;
+        mag[i * 3 + j] = fabs(vit[j]);
+      }
+      vit_prev[0] = vit[0]; vit_prev[1] = vit[1]; vit_prev[2] = vit[2];
+    }
+    tb[nobs - 1] = 0;
+    for (long i = 1; i < nobs; i++) tb[nobs - i - 1] = from[(nobs - i) * 3 + tb[nobs - i]];
+    for (long i = 1; i < nobs; i++) {
+      const double mg = marg[i * 3 + tb[i]];
+      if (!(mg < HUGE_VAL)) continue;
+      ++*decisions;
+      if (mg == 0.0) { ++*ties; continue; }
+      for (int q = 0; q < n_thr; q++) if (mg < thresholds[q]) ++below[q];
+      if (mg < *min_margin) { *min_margin = mg; *scale_at_min = mag[i * 3 + tb[i]]; }
+    }
+    free(from); free(marg); free(mag); free(tb);
+  }
+}
+
 #include "edo_fit.inc"
 
 /* =====================================================================================

@@ -186,6 +186,40 @@ def hmm(transitions, loglikelihood, positions, expected_cnv_length, nstates=3):
     return path.astype(np.int64), calls[:nc].copy()
 
 
+MARGIN_THRESHOLDS = (1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-3)
+
+
+def callcnvs_margins(likelihood, chrom_off, start, end, transition_probability=1e-4, expected_cnv_length=50000.0, acc=None):
+    """Decision margins along the Viterbi path of one sample (edo_callcnvs_margins): accumulates into / returns a dict with `decisions` (on-path
+    decisions between two finite candidates), `ties` (margin exactly 0), `below` {threshold: count of non-zero margins below it}, `min_margin`,
+    `scale_at_min` (|best candidate| there)."""
+    ll = np.asarray(likelihood, dtype=np.float64)
+    n = ll.shape[0]
+    llc = _f64(ll.T.ravel())
+    chrom_off = _i32(chrom_off)
+    thr = np.array(MARGIN_THRESHOLDS, dtype=np.float64)
+    below = np.zeros(thr.size, dtype=np.int64)
+    ties, dec = C.c_long(0), C.c_long(0)
+    mn, sc = C.c_double(np.inf), C.c_double(0.0)
+    L = lib()
+    if not getattr(L, "_margins_typed", False):
+        L.edo_callcnvs_margins.argtypes = [_dp, C.c_long, _ip, C.c_int, _ip, _ip, C.c_double, C.c_double, _dp, C.c_int,
+                                           np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"), C.POINTER(C.c_long), C.POINTER(C.c_long),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.edo_callcnvs_margins.restype = None
+        L._margins_typed = True
+    L.edo_callcnvs_margins(llc, n, chrom_off, chrom_off.size - 1, _i32(start), _i32(end), float(transition_probability), float(expected_cnv_length),
+                           thr, thr.size, below, C.byref(ties), C.byref(dec), C.byref(mn), C.byref(sc))
+    out = acc if acc is not None else {"decisions": 0, "ties": 0, "below": {("%g" % t): 0 for t in MARGIN_THRESHOLDS}, "min_margin": float("inf"), "scale_at_min": 0.0}
+    out["decisions"] += dec.value
+    out["ties"] += ties.value
+    for t, b in zip(MARGIN_THRESHOLDS, below):
+        out["below"]["%g" % t] += int(b)
+    if mn.value < out["min_margin"]:
+        out["min_margin"], out["scale_at_min"] = mn.value, sc.value
+    return out
+
+
 def callcnvs(likelihood, chrom_off, start, end, transition_probability=1e-4, expected_cnv_length=50000.0):
     """reference R/class_definition.R:343-374, :408-414 on pre-ordered exons.  likelihood (n,3) in
     (deletion, normal, duplication) order.  Returns (path int8[n], calls (ncalls,4))."""

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--counts-bits", type=int, default=32, help="16: the device counts as uint16 (ed_batch_set_counts_bits; tables mode)")
     ap.add_argument("--seed", type=int, default=20250621)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--margins", action="store_true", help="also: for every decision ON the reference's Viterbi path (the state the path is in at an "
+                    "observation choosing its predecessor, reference src/hmm.cpp:78-85) the gap between the winning and the runner-up candidate -- how far the "
+                    "emission differences of the table mode are from moving a back-pointer (oracle/ed_oracle.c: edo_callcnvs_margins)")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -94,8 +97,10 @@ def main():
         mine = calls[first[s]:first[s + 1]]
         g = {tuple(int(v) for v in row) for row in zip(mine["start_exon"] + 1, mine["end_exon"] + 1, mine["type"], mine["nexons"])}
         w = {tuple(int(v) for v in row[:4]) for row in ecalls}
+        mg = eo.callcnvs_margins(ell, chrom_off, start, end) if args.margins else None
         return (int(np.sum(~rel_ok)), int(np.sum(floor_ok & ~rel_ok)), mx, int(np.sum(got.view(np.int64) == ell.view(np.int64))),
-                int(np.sum(path[:, s].astype(np.int8) != epath)), len(g ^ w), len(w), float(np.min(np.abs(ell[m]))) if m.any() else 0.0)
+                int(np.sum(path[:, s].astype(np.int8) != epath)), len(g ^ w), len(w), float(np.min(np.abs(ell[m]))) if m.any() else 0.0, mg,
+                float(np.max(d[m])) if m.any() else 0.0)
 
     nthr = args.threads or max(1, min(64, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) - 1))
     with ThreadPoolExecutor(nthr) as ex:            # the checker is a C call: the GIL is released
@@ -118,6 +123,21 @@ def main():
            "expected_range": [float(np.min(p)), float(np.max(p))], "phi_range": [float(np.min(phi)), float(np.max(phi))],
            "table_stats": tstats, "samples_on_tables": n_tab,
            "cpu_threads": nthr, "cpu_seconds_wall": time.time() - t0}
+    if args.margins:
+        mgs = [r[8] for r in res]
+        k = int(np.argmin([g["min_margin"] for g in mgs]))
+        out["decision_margins"] = {
+            "what": "every observation of every chain: the state the reference's Viterbi path is in chooses its predecessor among three candidates "
+                    "(proba + vit[k]) + log(trans[k]), first strict maximum (reference src/hmm.cpp:78-85); margin = best - runner-up, on the checker's "
+                    "libm-flavour matrix (= the reference's arithmetic)",
+            "on_path_decisions": sum(g["decisions"] for g in mgs), "exact_ties": sum(g["ties"] for g in mgs),
+            "nonzero_margins_below": {t: sum(g["below"][t] for g in mgs) for t in mgs[0]["below"]},
+            "min_nonzero_margin": mgs[k]["min_margin"], "abs_score_at_that_decision": mgs[k]["scale_at_min"], "column_of_the_minimum": k,
+            "max_abs_loglik_difference_device_vs_reference": max(r[9] for r in res),
+            "reading": "a back-pointer can only differ between the device's table-mode matrix and the reference's if the candidates' difference moves by "
+                       "more than the margin; the two matrices differ by at most max_abs_loglik_difference per emission, and two candidates of one decision "
+                       "share the emission of the observation itself -- what separates them is the difference of two accumulated scores over the stretch "
+                       "where their paths differ"}
     print(json.dumps(out))
 
 
