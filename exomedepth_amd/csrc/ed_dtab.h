@@ -126,4 +126,73 @@ ED_PM_FN double ed_dtab_combine(double d1, double d2, double d3)
   return t.hi + (t.lo + s.lo);
 }
 
+/* ---- beyond the tables: D(x0, k) for large k from Stirling's series (round 6) ---------------------------------------------------------------
+ * A table costs an entry per count; deep sequencing (reference counts in the thousands and tens of thousands) outgrows what a workgroup can hold in
+ * LDS and then what is worth building at all.  For k >= 64 the same function is cheap to evaluate directly:
+ *     D(x0, k) = lgamma(z) - lgamma(x0),   z = fl(x0 + k)   (the reference's own rounded argument, src/CNV_estimate.cpp:49),
+ *     lgamma(z) = (z - 1/2) log z - z + log(2 pi)/2 + 1/(12 z) - 1/(360 z^3) + 1/(1260 z^5) - ...      (the next term is below 2e-16 for z >= 64)
+ * with lgamma(x0) a per-(sample, state, table) constant carried as a double-double (ed_dtab_lg0).  What is kept of the precision: the product
+ * (z - 1/2) log z exactly (fma), the sums as TwoSums, the logarithm to its own 0.52 ulp -- z times that is the error that remains, ~1 ulp of D
+ * (the table entries: 0.5 ulp).  An emission still is ed_dtab_combine of three such numbers.
+ * The same text is compiled into the emission kernel and into the checker (edo_dtab_tail); tests/test_dtab.py compares both with mpmath. */
+#define ED_DTAB_HALF_LOG_2PI_HI 0x1.d67f1c864beb5p-1
+#define ED_DTAB_HALF_LOG_2PI_LO -0x1.65b5a1b7ff5dfp-55
+#define ED_DTAB_TAIL_FROM 64            /* tails serve indices k >= this (every table window is at least this long) */
+
+/* lgamma(x0) as a double-double, x0 positive and normal: shifted up by 64 -- lgamma(x0) = lgamma(x0 + 64) - sum_{i<64} log(x0 + i), the sum in
+ * double-double with ed_ddlog_t, lgamma(x0 + 64) from the series above with seven terms and a double-double logarithm.  Sequential: one definition
+ * for the device (a lane per state in k_tab_build) and the checker. */
+ED_PM_FN ed_dd ed_dtab_lg0(double x0, const double* T)
+{
+  /* (the arguments x0 + i are NOT exact here, unlike a table's, whose definition is the sum over the rounded arguments: what the sum misses of
+   *  log(x0 + i) is (x0 + i - fl(x0 + i)) / fl(x0 + i) to first order, the next order being below 2^-106) */
+  ed_dd acc = ed_dd_make(0.0, 0.0);
+  double fix = 0.0;
+  for (int i = 0; i < 64; ++i) {
+    const ed_dd a = ed_two_sum(x0, (double)i);
+    acc = ed_dd_add_fast(acc, ed_ddlog_t(a.hi, T));
+    fix += a.lo / a.hi;
+  }
+  acc = ed_dd_add(acc, ed_dd_make(fix, 0.0));
+  const ed_dd zs = ed_two_sum(x0, 64.0);
+  const double z = zs.hi;                                  /* lgamma(x0 + 64) = lgamma(z) + zs.lo psi(z) */
+  const ed_dd lz = ed_ddlog_t(z, T);
+  const double zm = z - 0.5;                               /* exact: z >= 64 */
+  /* (z - 1/2) (lz.hi + lz.lo): the leading product exactly, the rest in binary64 */
+  const double p = zm * lz.hi;
+  const double pe = ed_pm_fma(zm, lz.hi, -p);
+  ed_dd g = ed_two_sum(p, -z);
+  g.lo += pe + zm * lz.lo;
+  const double w = 1.0 / z, w2 = w * w;
+  double ser = 1.0 / 156.0;
+  ser = ed_pm_fma(ser, w2, -691.0 / 360360.0);
+  ser = ed_pm_fma(ser, w2, 1.0 / 1188.0);
+  ser = ed_pm_fma(ser, w2, -1.0 / 1680.0);
+  ser = ed_pm_fma(ser, w2, 1.0 / 1260.0);
+  ser = ed_pm_fma(ser, w2, -1.0 / 360.0);
+  ser = ed_pm_fma(ser, w2, 1.0 / 12.0);
+  g.lo += ser * w + ED_DTAB_HALF_LOG_2PI_LO;
+  g.lo += zs.lo * (lz.hi - 0.5 * w);
+  g = ed_dd_add(ed_fast_two_sum(g.hi, g.lo), ed_dd_make(ED_DTAB_HALF_LOG_2PI_HI, 0.0));
+  return ed_dd_add(g, ed_dd_make(-acc.hi, -acc.lo));
+}
+
+/* D(x0, k), k >= ED_DTAB_TAIL_FROM, given lg0 = ed_dtab_lg0(x0) */
+ED_PM_FN double ed_dtab_tail(double x0, double lg0_hi, double lg0_lo, double k, const double* T)
+{
+  const double z = x0 + k;
+  const double lz = ed_plog_core_t(z, 0, T);
+  const double zm = z - 0.5;                               /* exact */
+  const double p = zm * lz;
+  const double pe = ed_pm_fma(zm, lz, -p);
+  const ed_dd a = ed_two_sum(p, -z);                       /* (z - 1/2) log z - z */
+  const ed_dd b = ed_two_sum(a.hi, -lg0_hi);               /* ... - lgamma(x0) */
+  const double w = 1.0 / z, w2 = w * w;
+  double ser = 1.0 / 1260.0;
+  ser = ed_pm_fma(ser, w2, -1.0 / 360.0);
+  ser = ed_pm_fma(ser, w2, 1.0 / 12.0);
+  const double small = ((ED_DTAB_HALF_LOG_2PI_HI + ser * w) + (ED_DTAB_HALF_LOG_2PI_LO - lg0_lo)) + ((pe + a.lo) + b.lo);
+  return b.hi + small;
+}
+
 #endif /* ED_DTAB_H */

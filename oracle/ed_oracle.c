@@ -146,6 +146,19 @@ EDO_API void edo_ddlog_v(long n, const double *x, double *hi, double *lo)
   static const double T[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
   for (long i = 0; i < n; i++) { const ed_dd r = ed_ddlog_t(x[i], &T[0][0]); hi[i] = r.hi; lo[i] = r.lo; }
 }
+/* beyond the tables (ed_dtab.h: ed_dtab_lg0, ed_dtab_tail): lgamma(x0) as a double-double, and D(x0, k[i]) for counts k[i] >= 64 */
+EDO_API void edo_dtab_lg0(double x0, double *hi, double *lo)
+{
+  static const double T[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+  const ed_dd r = ed_dtab_lg0(x0, &T[0][0]);
+  *hi = r.hi; *lo = r.lo;
+}
+EDO_API void edo_dtab_tail_v(double x0, long n, const double *k, double *out)
+{
+  static const double T[ED_PM_LOGT_N][3] = ED_PM_LOGT_ROWS;
+  const ed_dd g = ed_dtab_lg0(x0, &T[0][0]);
+  for (long i = 0; i < n; i++) out[i] = ed_dtab_tail(x0, g.hi, g.lo, k[i], &T[0][0]);
+}
 EDO_API void edo_dtab_combine_v(long n, const double *d1, const double *d2, const double *d3, double *out)
 {
   for (long i = 0; i < n; i++) out[i] = ed_dtab_combine(d1[i], d2[i], d3[i]);

@@ -40,6 +40,10 @@ def lib():
         L.edo_dtab.argtypes = [C.c_double, C.c_long, _dp]
         L.edo_ddlog_v.argtypes = [C.c_long, _dp, _dp, _dp]
         L.edo_dtab_combine_v.argtypes = [C.c_long, _dp, _dp, _dp, _dp]
+        L.edo_dtab_lg0.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.edo_dtab_lg0.restype = None
+        L.edo_dtab_tail_v.argtypes = [C.c_double, C.c_long, _dp, _dp]
+        L.edo_dtab_tail_v.restype = None
         L.edo_lnbeta_v.argtypes = [C.c_int, C.c_long, _dp, _dp, _dp]
         L.edo_lnbeta_v.restype = C.c_long
         L.edo_sf_v.argtypes = [C.c_int, C.c_int, C.c_long, _dp, _dp, _ip]
@@ -106,6 +110,18 @@ def psin_any(x):
 def dtab(x0, n):
     """D(x0, k) = lgamma(x0 + k) - lgamma(x0), k = 0..n-1, as the table-driven emission mode tabulates it (csrc/ed_dtab.h)"""
     out = np.empty(int(n)); lib().edo_dtab(float(x0), int(n), out); return out
+
+
+def dtab_lg0(x0):
+    """lgamma(x0) as the double-double (hi, lo) the Stirling tails subtract (csrc/ed_dtab.h: ed_dtab_lg0)"""
+    hi, lo = C.c_double(0), C.c_double(0)
+    lib().edo_dtab_lg0(float(x0), C.byref(hi), C.byref(lo))
+    return hi.value, lo.value
+
+
+def dtab_tail(x0, k):
+    """D(x0, k) = lgamma(x0 + k) - lgamma(x0) for counts k >= 64 from Stirling's series (csrc/ed_dtab.h: ed_dtab_tail)"""
+    k = _f64(k); out = np.empty_like(k); lib().edo_dtab_tail_v(float(x0), k.size, k, out); return out
 
 
 def ddlog(x):

@@ -47,3 +47,35 @@ def test_combine_is_the_rounded_exact_sum(oracle):
     for a, b, c, g in zip(d1, d2, d3, got):
         t = mp.mpf(float(a)) + mp.mpf(float(b)) - mp.mpf(float(c))
         assert abs(mp.mpf(float(g)) - t) <= abs(t) * mp.mpf(2) ** -52
+
+
+def test_stirling_tails_against_mpmath(oracle):
+    """D(x0, k) beyond the tables (ed_dtab_tail): lgamma(fl(x0 + k)) - lgamma(x0) to ~1 ulp, for shape parameters from 1e-3 to 1e5 and counts from the
+    first served one (64) to 2^24; lgamma(x0) itself (ed_dtab_lg0) to double-double accuracy"""
+    rng = np.random.default_rng(6)
+    worst = 0.0
+    for x0 in (1.5e-3, 0.37, 1.0, 2.0, 22.3, 40.8, 178.123, 201.0, 1999.5, 7.0e4 + 0.25):
+        hi, lo = oracle.dtab_lg0(x0)
+        t0 = mp.loggamma(mp.mpf(x0))
+        assert abs(mp.mpf(hi) + mp.mpf(lo) - t0) <= mp.mpf(2) ** -60 * max(abs(t0), 1), x0      # (its series part is summed in binary64: ~1e-19 absolute, five orders below an entry's ulp)
+        k = np.unique(np.concatenate([[64, 65, 100, 1000, 2476, 2 ** 24], np.exp(rng.uniform(np.log(64), np.log(2.0 ** 24), 300)).astype(np.int64)])).astype(np.float64)
+        got = oracle.dtab_tail(x0, k)
+        for kk, g in zip(k, got):
+            z = mp.mpf(float(np.float64(x0) + np.float64(kk)))            # the rounded argument, as the reference forms it
+            t = mp.loggamma(z) - t0
+            # the series forms lgamma(z) and subtracts: what it can keep is an ulp of the LARGER of |lgamma(z)| and |D| (a table's entry: half an ulp of D
+            # itself -- for counts far below the shape parameter the tables are the better of the two, and the conditioning rule of the tail samples,
+            # edtab.inc: tab_cond_bound with tails, counts (x0 + k) log(x0 + k) for it)
+            big = max(abs(t), abs(mp.loggamma(z)))
+            ulp = mp.mpf(2) ** (mp.floor(mp.log(big, 2)) - 52)
+            worst = max(worst, float(abs(mp.mpf(float(g)) - t) / ulp))
+    assert worst < 2.5, worst
+
+
+def test_tails_continue_the_tables(oracle):
+    """where a table ends and the series takes over the two agree to the last bits (both approximate the same function: 0.5 ulp and ~1 ulp)"""
+    for x0 in (0.9, 22.3, 178.123, 201.0):
+        d = oracle.dtab(x0, 9000)
+        k = np.arange(64, 9000, dtype=np.float64)
+        t = oracle.dtab_tail(x0, k)
+        assert np.max(np.abs(t - d[64:]) / np.spacing(np.abs(d[64:]))) <= 3.0
