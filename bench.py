@@ -543,6 +543,9 @@ def regime_leg(ed, eddist, torch, dev, plan, chrom_off, start, end, E, S, depth,
     b, _, _ = co.batch(tk)
     b.n_samples = S
     tstats = b.table_stats() if o.get("emit_mode") else None
+    if tstats is not None and o.get("emit_mode") == 2:
+        probe = list(range(0, S, max(1, S // 32)))
+        tstats["tail_samples_of_%d_probed" % len(probe)] = sum(1 for s_ in probe if b.table_windows(s_)[3])
     stage, nr, _ = co.stage_ms_total()
     union, own = interval_union(co.emission_intervals())
     ver = None
@@ -553,7 +556,24 @@ def regime_leg(ed, eddist, torch, dev, plan, chrom_off, start, end, E, S, depth,
     co.close()
     cells = float(E) * S
     ms = el / steps * 1e3
-    return {"depth": depth, "samples": S, "ms_per_step": ms, "value": cells * steps / el, "ns_per_cell": ms * 1e6 / cells,
+    # the same steps with every sample on full-length tables (cohort option emit_tails = 0: round 5's form) where the depth makes the difference
+    tails_off = None
+    if o.get("emit_mode") == 2 and depth >= 400:
+        co2 = ed.Cohort(plan, S, n_batches, **{**o, "emit_tails": 0})
+        sub2 = (lambda: co2.submit(t_in, r_in, n_samples=S)) if fit else (lambda: co2.submit(t_in, r_in, phi=phi, expected=p, n_samples=S))
+        for _ in range(n_batches + 2):
+            sub2()
+        co2.drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tk2 = sub2()
+        co2.drain()
+        el2 = time.perf_counter() - t0
+        b2, _, _ = co2.batch(tk2)
+        tails_off = {"ms_per_step": el2 / steps * 1e3, "table_stats": b2.table_stats()}
+        co2.close()
+    return {"depth": depth, "samples": S, "ms_per_step": ms, "value": cells * steps / el, "ns_per_cell": ms * 1e6 / cells, "tails_off": tails_off,
             "emission_ms_chip": union / max(nr, 1), "emission_ms_own": own / max(nr, 1),
             "stage_ms": {k: v / max(nr, 1) for k, v in stage.items()},
             "table_stats": tstats, "cold_share": (tstats["n_cold_cells"] / cells if tstats else None), "verify": ver}

@@ -146,6 +146,8 @@ SYMBOLS = [
     ("ed_batch_copy_emit_tables", C.c_int, [_vp, _i64, C.POINTER(_i32), _vp, _i64]),
     ("ed_batch_n_cold_cells", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_batch_copy_table_dims", C.c_int, [_vp, _i64, C.POINTER(_i32)]),
+    ("ed_batch_copy_table_windows", C.c_int, [_vp, _i64, C.POINTER(_i32)]),
+    ("ed_batch_set_emit_tails", C.c_int, [_vp, C.c_int]),
     ("ed_batch_table_stats", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_cohort_table_status", C.c_int, [_vp, C.POINTER(_i64)]),
     ("ed_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),

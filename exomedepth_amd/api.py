@@ -449,12 +449,14 @@ class Batch:
                for i in range(min(int(cap), nbad.value))]
         return ncmp.value, nbad.value, rec
 
-    def set_emit_mode(self, mode, cap_obs=None, cap_ref=None, reach=None):
+    def set_emit_mode(self, mode, cap_obs=None, cap_ref=None, reach=None, tails=None):
         """mode 0 / "strict": GSL's arithmetic operation for operation (default); 1 / "tables": log-gamma difference tables per
         (sample, state) -- three gathers and a sum per cell, ~1e-14 relative (see ed_batch_set_emit_mode)."""
         m = {"strict": 0, "tables": 1, "tables-sm": 2}.get(mode, mode)
         if cap_obs is not None or cap_ref is not None or reach is not None:
             check(lib().ed_batch_set_emit_tables(self.handle, int(cap_obs or 4096), int(cap_ref or 32768), float(reach or 8.0)))
+        if tails is not None:
+            self.set_emit_tails(tails)
         check(lib().ed_batch_set_emit_mode(self.handle, int(m)))
 
     def set_counts_layout(self, layout):
@@ -510,6 +512,16 @@ class Batch:
         d = (C.c_int32 * 4)()
         check(lib().ed_batch_copy_table_dims(self.handle, int(sample), d))
         return tuple(int(x) for x in d)
+
+    def table_windows(self, sample):
+        """(n1, n2, n3, tail) of one sample in the last run (ed_batch_copy_table_windows): the LDS windows of the sample-major table mode and whether
+        the sample is a tail sample (Stirling's series beyond the windows)"""
+        d = (C.c_int32 * 4)()
+        check(lib().ed_batch_copy_table_windows(self.handle, int(sample), d))
+        return tuple(int(x) for x in d)
+
+    def set_emit_tails(self, on=True):
+        check(lib().ed_batch_set_emit_tails(self.handle, int(bool(on))))
 
     def device_pointers(self):
         L = lib()

@@ -174,7 +174,7 @@ __global__ void k_sample_consts(const double* __restrict__ phi, const double* __
   // the accessors and the call decoration read later -- written here instead of by two device-to-device copies on the emission stream
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (z_nerr && s < 8) z_nerr[s] = 0ull;
-  if (z_notab && s == 0) z_notab[0] = 0u;
+  if (z_notab && s == 0) { z_notab[0] = 0u; z_notab[S + 1] = 0u; }      // samples without tables; tail samples (edtab.inc)
   if (z_cold_n) for (int64_t i = s; i < n_cold_n; i += (int64_t)gridDim.x * blockDim.x) z_cold_n[i] = 0u;
   if (s >= S) return;
   if (z_tacc) { z_tacc[s] = 0ull; z_tacc[S + s] = 0ull; z_tacc[2 * S + s] = 0ull; }
@@ -1663,6 +1663,18 @@ __global__ void k_eval_sf(int which, int64_t n, const double* __restrict__ x, co
     case 12: { double sg; unsigned st; r = edsf::lngamma_sgn_any(x[i], &sg, &st); } break;
     case 13: { double sg; unsigned st; (void)edsf::lngamma_sgn_any(x[i], &sg, &st); r = sg + 8.0 * (double)st; } break;
     case 14: r = ed_psin_any(x[i]); break;
+    case 15: { double a, b; edfit::digamma_trigamma_nolog_big(x[i], a, b); r = edfit::flog(x[i]) + a; } break;      // the short series of the fit's large arguments (x >= 32)
+    case 16: { double a, b; edfit::digamma_trigamma_nolog_big(x[i], a, b); r = b; } break;
+    case 17: {                                                                                                       // one cell through accumulate_cell_run, short series: d/da
+      edfit::Acc c = {0, 0, 0, 0, 0}; double pa = 1.0, pb = 1.0;
+      edfit::accumulate_cell_run(c, pa, pb, x[i], 4.0 * x[i], 5.0 * x[i], (int)y[i], 9 * (int)y[i], fmin(x[i] + y[i], 4.0 * x[i] + 8.0 * y[i]) >= 32.0);
+      r = c.ga + edfit::flog(pa);
+    } break;
+    case 18: {                                                                                                       // ... the full series
+      edfit::Acc c = {0, 0, 0, 0, 0}; double pa = 1.0, pb = 1.0;
+      edfit::accumulate_cell_run(c, pa, pb, x[i], 4.0 * x[i], 5.0 * x[i], (int)y[i], 9 * (int)y[i], false);
+      r = c.ga + edfit::flog(pa);
+    } break;
     default: r = ed_pm_nan();
   }
   out[i] = r;
@@ -1776,10 +1788,13 @@ struct ed_batch {
   int tab_tw = 16;               // samples per tile of k_emit_tab (16 / 32 / 64)
   int tab_capY = 4096, tab_capR = 32768;   // longest obs / ref table of a sample (entries); the tot table has their sum
   double tab_reach = 8.0;        // a table covers this multiple of the sample's mean count (+ 64)
+  int tab_tails = 1;             // emit mode 2: samples whose counts outgrow the LDS windows are served by Stirling's series beyond them (ed_batch_set_emit_tails)
   int64_t tab_stride = 0;        // entries between the tables of consecutive samples = 2 (capY + capR)
   double* d_tabs = nullptr;      // [S][tab_stride][3]
   int4* d_tdims = nullptr;       // [S + 64] (Ly, Lr, Tm1, reason) per sample (edtab.inc: tab_dims_of)
-  unsigned int* d_notab = nullptr;   // [1 + S] samples without tables: their number, then the samples (k_tab_build)
+  unsigned int* d_notab = nullptr;   // [2][1 + S] samples without tables: their number, then the samples; the same for the tail samples (k_tab_build)
+  int4* d_twins = nullptr;           // [S] (n1, n2, n3, tail): the LDS windows of the sample-major form, and whether the sample is a tail sample (edtab.inc)
+  double* d_tlg0 = nullptr;          // [S][3 tables][3 states][2] log Gamma of the tables' shape parameters (double-doubles): what a tail sample's series subtract
   unsigned long long* d_tacc = nullptr;   // [3][S] subsampled count sums (k_tab_stats)
   uint2* d_cold_list = nullptr;  // cells outside their sample's tables
   unsigned int* d_cold_n = nullptr;
@@ -2278,7 +2293,7 @@ ED_EXPORT void ed_batch_destroy(ed_batch* b)
   if (!b) return;
   fitwork_free(b->fitw);
   binswork_free(b->binsw);
-  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_notab, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t, b->d_test_sm, b->d_ref_sm, b->d_loglik_sm, b->d_blk_sm, b->d_vit_queue};
+  void* ptrs[] = {b->d_job_off, b->d_job_chrom, b->d_seg, b->d_maps, b->d_ent, b->d_last, b->d_ppath, b->d_loglik, b->d_path, b->d_bp, b->d_consts, b->d_tab_gl, b->d_tab_lg, b->d_cflags, b->d_counts, b->d_offsets, b->d_total, b->d_nerr, b->d_calls, b->d_info, b->d_ctab, b->d_left_out, b->d_tabs, b->d_tdims, b->d_twins, b->d_tlg0, b->d_notab, b->d_tacc, b->d_cold_list, b->d_cold_n, b->d_seg_t, b->d_test_sm, b->d_ref_sm, b->d_loglik_sm, b->d_blk_sm, b->d_vit_queue};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->job_ev) if (e) (void)hipEventDestroy(e);
@@ -2413,7 +2428,8 @@ static int64_t tab_rows_per_wg(int tw) { return 4 * (64 / tw); }
 
 static void tab_release(ed_batch* b)
 {
-  void** ptrs[] = {(void**)&b->d_tabs, (void**)&b->d_tdims, (void**)&b->d_notab, (void**)&b->d_tacc, (void**)&b->d_cold_list, (void**)&b->d_cold_n, (void**)&b->d_seg_t};
+  void** ptrs[] = {(void**)&b->d_tabs, (void**)&b->d_tdims, (void**)&b->d_notab, (void**)&b->d_tacc, (void**)&b->d_cold_list, (void**)&b->d_cold_n, (void**)&b->d_seg_t,
+                   (void**)&b->d_twins, (void**)&b->d_tlg0};
   for (void** q : ptrs) { if (*q) (void)hipFree(*q); *q = nullptr; }
   (void)hipGetLastError();
 }
@@ -2428,7 +2444,9 @@ static int tab_setup(ed_batch* b)
   if ((int64_t)b->tab_tw * b->tab_stride * 24 >= ((int64_t)1 << 31))
     return ed_fail(ED_ERR_INVALID, "emit mode 1: %d samples x %lld table entries x 24 bytes per tile exceed 2^31 (smaller table caps or tile width)",
                    b->tab_tw, (long long)b->tab_stride);
-  b->cold_cap = (unsigned int)std::min<int64_t>(std::max<int64_t>(E * S / 32, 1 << 16), (int64_t)1 << 28) / kColdLists * kColdLists;
+  // (a sixteenth of the cells: the lists of round 5 -- a thirty-second -- ran out at 1 600 reads per exon, where 2 % of the cells lie beyond the conditioning limit,
+  //  and the strict pass then walked all 2 x 10^8 cells again: 7.6 ms)
+  b->cold_cap = (unsigned int)std::min<int64_t>(std::max<int64_t>(E * S / 16, 1 << 16), (int64_t)1 << 28) / kColdLists * kColdLists;
   // segments in job order, workgroups numbered for k_emit_tab's tile (rows x tab_tw samples), as ed_batch_create does for k_emit_batch
   const int64_t rows = tab_rows_per_wg(b->tab_tw), nsb = (S + b->tab_tw - 1) / b->tab_tw;
   int64_t blk = 0;
@@ -2445,13 +2463,16 @@ static int tab_setup(ed_batch* b)
   auto A = [&](void** q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 1) != hipSuccess) { ok = false; *q = nullptr; } };
   A((void**)&b->d_tabs, (size_t)S * b->tab_stride * 24);
   A((void**)&b->d_tdims, (size_t)(S + 64) * 16);
-  A((void**)&b->d_notab, (size_t)(S + 1) * 4);
+  A((void**)&b->d_notab, (size_t)2 * (S + 1) * 4);
+  A((void**)&b->d_twins, (size_t)(S + 64) * 16);
+  A((void**)&b->d_tlg0, (size_t)S * 18 * 8);
   A((void**)&b->d_tacc, (size_t)3 * S * 8);
   A((void**)&b->d_cold_list, (size_t)b->cold_cap * 8);
   A((void**)&b->d_cold_n, (size_t)(kColdLists + 1) * 4);
   A((void**)&b->d_seg_t, b->seg_t.size() * 8);
   if (ok && hipMemset(b->d_tdims, 0, (size_t)(S + 64) * 16) != hipSuccess) ok = false;
-  if (ok && hipMemset(b->d_notab, 0, (size_t)(S + 1) * 4) != hipSuccess) ok = false;
+  if (ok && hipMemset(b->d_notab, 0, (size_t)2 * (S + 1) * 4) != hipSuccess) ok = false;
+  if (ok && hipMemset(b->d_twins, 0, (size_t)(S + 64) * 16) != hipSuccess) ok = false;
   if (ok && hipMemcpy(b->d_seg_t, b->seg_t.data(), b->seg_t.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
   if (ok && ed_null_stream_fence() != hipSuccess) ok = false;
   if (!ok) {
@@ -2535,6 +2556,7 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
   if (int rc = tab_setup(b)) return rc;
   const int64_t E = b->plan->E, S = b->S;
   const int step = E >= 4096 ? 16 : 1;     // (d_tacc, d_notab[0], d_cold_n were zeroed by k_sample_consts, launched right before this on the same stream)
+  const int tails = (b->emit_mode == 2 && b->tab_tails) ? 1 : 0;      // tail samples exist in the sample-major form only (edtab.inc: tab_windows)
   if (E > 0 && b->counts_layout == 1)
     hipLaunchKernelGGL(k_tab_stats_sm, dim3((unsigned)S, 4), dim3(64), 0, st, d_test, d_ref, E, E, S, step, b->d_tacc, b->cb());
   else if (E > 0)
@@ -2542,10 +2564,10 @@ static int tab_build(ed_batch* b, const int32_t* d_test, const int32_t* d_ref, h
                        step, b->d_tacc);
   if (S < 256 && ED_TAB_BUILD_THREADS == 64)
     hipLaunchKernelGGL(k_tab_build<256>, dim3((unsigned)S, 3), dim3(256), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach, b->tab_capY, b->tab_capR,
-                       b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab);
+                       b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab, tails, b->d_twins, b->d_tlg0);
   else
     hipLaunchKernelGGL(k_tab_build<ED_TAB_BUILD_THREADS>, dim3((unsigned)S, 3), dim3(ED_TAB_BUILD_THREADS), 0, st, b->d_consts, b->d_cflags, b->d_tacc, b->tab_reach,
-                       b->tab_capY, b->tab_capR, b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab);
+                       b->tab_capY, b->tab_capR, b->d_tdims, S, b->d_tabs, b->tab_stride, b->d_notab, tails, b->d_twins, b->d_tlg0);
   HIP_TRY(hipGetLastError());
   return ED_OK;
 }
@@ -2650,12 +2672,21 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       if (const char* e = ed_knob("ED_SM_NSPLIT")) { if (atoi(e) > 0) nsplit = atoi(e); }
       nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(nsplit, n / 32));
       const int64_t nwg = ((S + 7) / 8) * 8 * nsplit;
-      if (cl1 && cb == 2)
+      const unsigned ntw = (unsigned)std::min<int64_t>(nwg, 1024);      // the tail samples' persistent grid (returns at once when the slab has none)
+      if (cl1 && cb == 2) {
         hipLaunchKernelGGL(k_emit_tab_sm<2>, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, d_test, d_ref, b->d_tdims, b->d_tabs, b->tab_stride,
-                           b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap);
-      else
-      hipLaunchKernelGGL(k_emit_tab_sm<4>, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
-                         b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap);
+                           b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_twins);
+        if (b->tab_tails)
+          hipLaunchKernelGGL(k_emit_tail_sm<2>, dim3(ntw), dim3(kSmBlock), 0, st, d_test, d_ref, b->d_tdims, b->d_twins, b->d_tlg0, b->d_consts, b->d_tabs, b->tab_stride,
+                             b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_notab + (S + 1));
+      } else {
+        hipLaunchKernelGGL(k_emit_tab_sm<4>, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
+                           b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_twins);
+        if (b->tab_tails)
+          hipLaunchKernelGGL(k_emit_tail_sm<4>, dim3(ntw), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_twins, b->d_tlg0,
+                             b->d_consts, b->d_tabs, b->tab_stride, b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n,
+                             b->cold_cap, b->d_notab + (S + 1));
+      }
       return;
     }
     const uint32_t nsb = (uint32_t)((S + b->tab_tw - 1) / b->tab_tw);
@@ -3374,8 +3405,12 @@ try {
   if (int rc = batch_ready(b)) return rc;
   if (!dims || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_emit_tables: bad arguments");
   if (!b->d_tabs || b->emit_mode < 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_emit_tables: the batch does not run a table-driven emit mode");
-  int4 d;
+  int4 d, w;
   if (int rc = ed_d2h(&d, b->d_tdims + sample, 16, b->stream)) return rc;
+  if (int rc = ed_d2h(&w, b->d_twins + sample, 16, b->stream)) return rc;
+  // (a tail sample's tables are its LDS windows, back to back: the lengths reported are the BUILT ones -- obs n1, ref n2 -- and of the n1 + n2
+  //  entries of the tot table's slice only the first n3 are made: ed_batch_copy_table_windows)
+  if (w.w) { d.x = w.x; d.y = w.y; }
   dims[0] = d.x; dims[1] = d.y;
   const int64_t n = std::min<int64_t>(2 * ((int64_t)d.x + d.y), cap_entries);
   if (n > 0) {
@@ -3385,6 +3420,31 @@ try {
   return ED_OK;
 }
 ED_CATCH("ed_batch_copy_emit_tables")
+
+// sample-major table mode: (n1, n2, n3, tail) of one sample in the last run -- the entries of its obs / ref / tot table a workgroup keeps in LDS, and
+// whether it is a tail sample (its counts outgrow the windows: tables built for the windows only, Stirling's series beyond, served up to the
+// conditioning limit that ed_batch_copy_table_dims then reports as Ly / Lr)
+ED_EXPORT int ed_batch_copy_table_windows(ed_batch* b, int64_t sample, int32_t out[4])
+try {
+  if (int rc = batch_ready(b)) return rc;
+  if (!out || sample < 0 || sample >= b->S) return ed_fail(ED_ERR_INVALID, "ed_batch_copy_table_windows: bad arguments");
+  if (!b->d_tabs || b->emit_mode < 1) return ed_fail(ED_ERR_STATE, "ed_batch_copy_table_windows: the batch does not run a table-driven emit mode");
+  int4 w;
+  if (int rc = ed_d2h(&w, b->d_twins + sample, 16, b->stream)) return rc;
+  out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w;
+  return ED_OK;
+}
+ED_CATCH("ed_batch_copy_table_windows")
+
+// emit mode 2: 1 (default) = samples whose counts outgrow the LDS windows are tail samples (edtab.inc); 0 = every sample on full-length tables
+// (round 5's behaviour: look-ups beyond the windows in global memory, cells beyond the length caps on the strict lists)
+ED_EXPORT int ed_batch_set_emit_tails(ed_batch* b, int on)
+try {
+  if (!b) return ed_fail(ED_ERR_INVALID, "NULL batch");
+  b->tab_tails = on ? 1 : 0;
+  return ED_OK;
+}
+ED_CATCH("ed_batch_set_emit_tails")
 
 // table-driven modes: what the last run left to the strict arithmetic
 //   out[0] cells on the strict lists (outside their sample's tables, or under its few-reads rule), summed over the run's launch groups

@@ -337,6 +337,16 @@ int ed_batch_verify_emissions_tol(ed_batch* batch, const int32_t* d_test, const 
  * samples without tables.  ed_batch_n_cold_cells = out[0]. */
 int ed_batch_copy_emit_tables(ed_batch* batch, int64_t sample, int32_t dims[2], double* entries, int64_t cap_entries);
 int ed_batch_copy_table_dims(ed_batch* batch, int64_t sample, int32_t dims[4]);
+/* Sample-major table mode (emit mode 2), one sample of the last run: out = (n1, n2, n3, tail).  n1 / n2 / n3: the entries of its obs / ref / tot table
+ * a workgroup keeps in LDS.  tail = 1: a TAIL sample -- its counts outgrow those windows (mean total >= 1.25 x the tot window: ~250 reads per exon and
+ * test sample upwards with 8 x deeper references); its tables are built for the windows only, an index beyond a window is served by Stirling's series
+ * (csrc/ed_dtab.h: ed_dtab_tail) and its cells are served up to the conditioning limit, which ed_batch_copy_table_dims then reports as Ly / Lr.
+ * ed_batch_copy_emit_tables reports a tail sample's BUILT lengths (n1, n2); of its tot slice the first n3 entries are made. */
+int ed_batch_copy_table_windows(ed_batch* batch, int64_t sample, int32_t out[4]);
+/* 1 (default): tail samples as above; 0: every sample on full-length tables (look-ups beyond the windows in global memory, cells beyond the length
+ * caps of ed_batch_set_emit_tables on the strict lists -- round 5's behaviour; the time per cell then grows with the depth: 2.2 x at 400 reads per
+ * exon, 7 x at 1 600).  Values within the same 1e-10 of the reference's arithmetic either way.  Cohort option "emit_tails". */
+int ed_batch_set_emit_tails(ed_batch* batch, int on);
 int ed_batch_table_stats(ed_batch* batch, int64_t out[4]);
 int ed_batch_n_cold_cells(ed_batch* batch, int64_t* n_cells);
 
@@ -498,6 +508,7 @@ int ed_get_power_betabinom_mode(int64_t n, const double* size, const double* phi
  *                      them that way, and host-fed slabs in layout 1 (R's column-major matrix) are uploaded without a transposition
  *   "counts_bits"      32 (default) / 16: ed_batch_set_counts_bits for every slab of ed_cohort_submit -- device-resident uint16 counts (needs
  *                      counts_layout 1 and emit_mode 2).  Host-fed slabs choose their device format themselves, see "host_narrow"
+ *   "emit_tails"       1 (default) / 0: ed_batch_set_emit_tails for every slab (emit_mode 2)
  *   "host_narrow"      1 (default) / 0: host-fed slabs of a cohort with emit_mode 2 + counts_layout 1 stay 16 bits wide on the device whenever
  *                      their counts fit -- uint16 host blocks go up as they lie, int32 blocks in pageable memory (R's integer matrices) are
  *                      narrowed by the host threads that stage them: 2 bytes per count on the link, no widening pass.  A slab holding a count
@@ -645,7 +656,9 @@ int ed_synchronize(void* stream);
  * which: 0 lnbeta(x,y)  1 portable log(x)  2 portable exp(x)  3 sqrt(x)  4 x/y  5 portable sin(x) on [0,pi]
  *        6 digamma(x)  7 trigamma(x)  8 in-range exact division x/y  9 exp for |x| < ln2/2  10 log, fast path
  *        11 error sites of lnbeta(x,y) (see ed_get_loglike_matrix_messages)  12 log|Gamma(x)| for any x
- *        13 sign of Gamma(x) + 8 * its error site  14 portable sin(x), |x| < 2^52 */
+ *        13 sign of Gamma(x) + 8 * its error site  14 portable sin(x), |x| < 2^52
+ *        15 digamma(x), 16 trigamma(x) by the fit's short series (x >= 32)  17 / 18 d/da of one cell's log-likelihood term at (a, b, a + b) =
+ *        (x, 4x, 5x), (y, n) = (y, 9y) through the batched fit's cell routine, short series where its arguments allow / long series */
 int ed_eval_sf(int which, int64_t n, const double* x, const double* y, double* out);
 
 #ifdef __cplusplus

@@ -28,6 +28,18 @@ def test_device_digamma_trigamma(edlib, oracle):
     assert np.max(np.abs(got1 - psi1) / np.abs(psi1)) < 5e-15
 
 
+def test_short_series_of_the_batched_fit(edlib):
+    """the reference-set searches' batched per-cell fit (k_fit_accum) evaluates digamma / trigamma of arguments >= 32 with four Bernoulli terms instead of
+    seven: the same values to the last bits, also through the cell routine with lanes of either kind side by side"""
+    rng = np.random.default_rng(8)
+    x = np.exp(rng.uniform(np.log(32.0), np.log(1e7), 5000))
+    assert np.max(np.abs(eval_sf(edlib, 15, x) - eval_sf(edlib, 6, x)) / np.abs(eval_sf(edlib, 6, x))) < 5e-16
+    assert np.max(np.abs(eval_sf(edlib, 16, x) - eval_sf(edlib, 7, x)) / eval_sf(edlib, 7, x)) < 5e-16
+    a = np.exp(rng.uniform(np.log(0.5), np.log(3000), 8192)); y = rng.integers(0, 4000, 8192).astype(float)
+    d = eval_sf(edlib, 17, a, y) - eval_sf(edlib, 18, a, y)
+    assert np.max(np.abs(d)) < 1e-14
+
+
 def _fit_case(edlib, oracle, E, S, seed, geometry=None, **kw):
     from exomedepth_amd import synth
     chrom_off, start, end = synth.exon_design(E, 4, seed)

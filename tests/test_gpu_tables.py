@@ -139,7 +139,8 @@ def test_cells_beyond_the_tables_carry_the_strict_bits(edlib, mode):
     test[5, 3] = -4                      # a negative count: outside every table; NaN + error events as strict mode
     plan = ed.Plan(chrom_off, start, end)
     for reach, cap_obs, cap_ref in ((1.0, 64, 64), (1.0, 128, 1024), (8.0, 4096, 32768)):
-        r = run_modes(plan, S, test, ref, phi, p, mode, cap_obs=cap_obs, cap_ref=cap_ref, reach=reach)
+        # (tails off: with tables this short against counts this deep the samples would be tail samples, served by the series wherever the tables end)
+        r = run_modes(plan, S, test, ref, phi, p, mode, cap_obs=cap_obs, cap_ref=cap_ref, reach=reach, tails=0)
         b = r[1]["batch"]
         ll0, ll1 = r[0]["ll"], r[1]["ll"]
         out, notab = not_served(b, test, ref)
@@ -621,4 +622,115 @@ def test_whole_columns_of_the_headline_geometries(edlib, oracle, S, mode, layout
     assert sum(r[0] for r in res) == 0, "log-likelihoods beyond the tolerance"
     assert sum(r[1] for r in res) == 0, "discordant Viterbi states"
     assert sum(r[2] for r in res) == 0, "discordant call rows"
+    b.close(); plan.close()
+
+
+# ---- tail samples (round 6): counts that outgrow the LDS windows of the sample-major form are served by Stirling's series (csrc/ed_dtab.h) ----------
+def _tail_check(oracle, b, test, ref, phi, p, plan, S, strict, expect_tail, beyond_the_limit=False):
+    ll = b.loglik()
+    wins = [b.table_windows(s) for s in range(S)]
+    assert [w[3] for w in wins] == list(expect_tail), [w[3] for w in wins]
+    st = b.table_stats()
+    out, _ = not_served(b, test, ref)
+    assert st["n_samples_without_tables"] == 0 and st["n_cold_cells"] == int(out.sum())
+    if not beyond_the_limit:
+        assert st["cold_list_overflow"] == 0
+        assert out.mean() < 0.02, out.mean()                      # the series serves up to the conditioning limit: next to nothing is left to the strict lists
+    sel = np.broadcast_to(out[:, None, :], ll.shape)
+    assert np.array_equal(bits(ll[sel]), bits(strict["ll"][sel]))     # ... and what is carries mode 0's bits
+    worst = 0.0
+    for s in range(S):
+        ell, _ = oracle.get_loglike_matrix(phi[s], p[s], test[:, s] + ref[:, s], test[:, s], 1.0, oracle.LIBM)
+        assert np.all(close_rel(ll[:, :, s], ell)), s
+        nz = ell != 0
+        worst = max(worst, float(np.max(np.abs(ll[:, :, s][nz] - ell[nz]) / np.abs(ell[nz]))))
+    assert np.array_equal(b.path(), strict["path"]) and np.array_equal(b.calls(), strict["calls"])
+    return wins, worst
+
+
+@pytest.mark.parametrize("depth", [400.0, 1600.0, 6000.0])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_tail_samples_at_depth(edlib, oracle, depth, layout):
+    """every sample a tail sample: windows in LDS, the series beyond, values within 1e-10 RELATIVE of the reference's arithmetic, the strict
+    mode's paths and calls; with the tails switched off (round 5's full-length tables) the same paths and calls"""
+    E, S = 6000, 40
+    chrom_off, start, end = synth.exon_design(E, 4, 31)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 31, n_segments=5, mean_depth=depth)
+    plan = ed.Plan(chrom_off, start, end)
+    b0 = ed.Batch(plan, S); b0.run(test, ref, phi, p)
+    strict = dict(ll=b0.loglik(), path=b0.path(), calls=b0.calls())
+    t_in, r_in = (np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T)) if layout else (test, ref)
+    b = ed.Batch(plan, S); b.set_emit_mode(2); b.set_counts_layout(layout)
+    b.run(t_in, r_in, phi, p)
+    # (6 000 reads per exon: totals of 50 000 and more, beyond where the conditioning rule lets the three-term sum stand in for the reference's value --
+    #  those cells take the strict arithmetic, lists run out or not)
+    wins, worst = _tail_check(oracle, b, test, ref, phi, p, plan, S, strict, [1] * S, beyond_the_limit=depth > 2000)
+    assert all(w[0] + w[1] + w[2] <= 6144 and min(w[:3]) >= 64 for w in wins)
+    ly, lr, t1, t2, t3 = b.emit_tables(0)                          # a tail sample's tables ARE its windows
+    assert (ly, lr) == wins[0][:2]
+    assert worst < 5e-12, worst
+    b2 = ed.Batch(plan, S); b2.set_emit_mode(2, tails=0); b2.set_counts_layout(layout)
+    b2.run(t_in, r_in, phi, p)
+    assert all(b2.table_windows(s)[3] == 0 for s in range(S))
+    assert np.array_equal(b2.path(), strict["path"]) and np.array_equal(b2.calls(), strict["calls"])
+    for x in (b0, b, b2):
+        x.close()
+    plan.close()
+
+
+def test_tail_and_table_samples_in_one_slab(edlib, oracle):
+    """shallow and deep samples side by side (70 and 1 500 reads per exon), 130 of them (ragged against every tile width), fitted on the device"""
+    E, S = 5000, 130
+    chrom_off, start, end = synth.exon_design(E, 3, 32)
+    deep = (np.arange(S) % 3 == 1)
+    ta, ra, pa, pha, _ = synth.counts_numpy(chrom_off, S, 32, n_segments=4, mean_depth=70.0)
+    tb_, rb_, pb, phb, _ = synth.counts_numpy(chrom_off, S, 33, n_segments=4, mean_depth=1500.0)
+    test = np.where(deep[None, :], tb_, ta).astype(np.int32); ref = np.where(deep[None, :], rb_, ra).astype(np.int32)
+    p = np.where(deep, pb, pa); phi = np.where(deep, phb, pha)
+    plan = ed.Plan(chrom_off, start, end)
+    b0 = ed.Batch(plan, S); b0.run(test, ref, phi, p)
+    strict = dict(ll=b0.loglik(), path=b0.path(), calls=b0.calls())
+    b = ed.Batch(plan, S); b.set_emit_mode(2); b.set_counts_layout(1)
+    b.run(np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T), phi, p)
+    _tail_check(oracle, b, test, ref, phi, p, plan, S, strict, deep.astype(int))
+    b.run(np.ascontiguousarray(test.T), np.ascontiguousarray(ref.T), phi, p)       # the object is reused: the tail list is rebuilt
+    _tail_check(oracle, b, test, ref, phi, p, plan, S, strict, deep.astype(int))
+    b0.close(); b.close(); plan.close()
+
+
+def test_tail_values_are_the_checkers(edlib, oracle):
+    """a tail sample's emissions, recomputed on the host from the shared definition: table entries inside the windows (edo_dtab), ed_dtab_tail beyond
+    them, ed_dtab_combine of the three -- the same bits (a table entry on a rounding boundary may sit an ulp off: the parallel scan's association)"""
+    E, S = 3000, 6
+    chrom_off, start, end = synth.exon_design(E, 2, 34)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, 34, n_segments=2, mean_depth=900.0)
+    plan = ed.Plan(chrom_off, start, end)
+    b = ed.Batch(plan, S); b.set_emit_mode(2)
+    b.run(test, ref, phi, p)
+    ll = b.loglik()
+    n_eq = n_all = 0
+    for s in (0, S - 1):
+        n1, n2, n3, tail = b.table_windows(s)
+        assert tail == 1
+        out, _ = not_served(b, test, ref)
+        e = p[s]
+        sd = np.sqrt((phi[s] * e) * (1.0 - e))
+        for st, odds in enumerate((0.5, 1.0, 1.5)):
+            ep = e if st == 1 else (e * odds) / ((e * odds + 1) - e)
+            a1 = ((ep * ep) * (1 - ep)) / (sd * sd) - ep
+            a2 = ((1 - ep) / ep) * a1
+            parts = []
+            for x0, idx, nwin in ((a1, test[:, s], n1), (a2, ref[:, s], n2), (a1 + a2, test[:, s] + ref[:, s], n3)):
+                tab = oracle.dtab(x0, nwin)
+                inside = idx < nwin
+                d = np.empty(E)
+                d[inside] = tab[idx[inside]]
+                d[~inside] = oracle.dtab_tail(x0, idx[~inside].astype(np.float64))
+                parts.append(d)
+            want = oracle.dtab_combine(*parts)
+            ok = ~out[:, s]
+            got = ll[ok, st, s]
+            n_eq += int(np.sum(bits(got) == bits(want[ok]))); n_all += int(ok.sum())
+            assert np.all(np.abs(got - want[ok]) <= 4 * np.spacing(np.abs(want[ok])))
+    assert n_eq >= 0.995 * n_all, (n_eq, n_all)
     b.close(); plan.close()
