@@ -311,6 +311,30 @@ def mode_leg(ed, torch, plan, test, ref, S, steps, fit, phi, p, opts, in_flight=
     return {"ms_per_step": el / steps * 1e3, "value": test.numel() * steps / el, "steps": steps}
 
 
+def r_entry_leg(ed, chrom_off, start, end, test, ref, S, steps, fit, phi, p):
+    """What the R-level .Call entry runs (shim/edcore_shim.c: edr_call_cnvs_batch): ed_multi_run_host on R's own matrices -- int32, column-major
+    exons x samples, PAGEABLE memory, wire = 4 -- in the sample-major table mode, one device, the wrapper's slab of 256 samples; with the narrowing of
+    round 6 (the host threads that stage a block make it uint16, the slab stays uint16 on the device) and with it switched off (round 5's path:
+    int32 on the link, int32 on the device).  ms per 1 024-sample cohort, call table collected."""
+    th = np.ascontiguousarray(test.t().contiguous().cpu().numpy(), dtype=np.int32)
+    rh = np.ascontiguousarray(ref.t().contiguous().cpu().numpy(), dtype=np.int32)
+    par = {} if fit else {"phi": phi.cpu().numpy(), "expected": p.cpu().numpy()}
+    out = {}
+    for name, narrow in (("narrowed_while_staged", 1), ("int32_on_link_and_device", 0)):
+        m = ed.MultiDevice(chrom_off, start, end, 256, devices=[0], emit_mode=2, counts_layout=1, host_narrow=narrow)
+        res = m.run_host(th, rh, 1, **par)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = m.run_host(th, rh, 1, **par)
+        el = time.perf_counter() - t0
+        out[name] = {"ms_per_cohort": el / steps * 1e3, "value": float(th.size) * steps / el, "n_calls": len(res["calls"]),
+                     "link_GBps": 2.0 * th.size * (2 if narrow else 4) * steps / el / 1e9}
+        m.close()
+    out["ratio"] = out["narrowed_while_staged"]["ms_per_cohort"] / out["int32_on_link_and_device"]["ms_per_cohort"]
+    out["same_call_count"] = out["narrowed_while_staged"]["n_calls"] == out["int32_on_link_and_device"]["n_calls"]
+    return out
+
+
 def staged_leg(ed, torch, plan, test, ref, phi, p, E, S, n_batches, args):
     """The same steps with the counts coming from HOST memory for every slab (ed_cohort_submit_host: copy stream, device slabs
     double-buffered by the slots, the 16-bit wire format widened on the device): the PCIe-inclusive rate.  Reported beside `value`,
@@ -1158,6 +1182,8 @@ def main():
     staged = None
     if world == 1 and args.stage_inputs and use_cohort:
         staged = leg(staged_leg, ed, torch, plan, test, ref, phi, p, E, S, min(n_batches, 2), args)     # (host-fed slabs: two / three slabs in flight, one lane -- the link is the bound)
+    if staged is not None and "error" not in staged and args.emit_mode == "tables" and args.counts_layout == 1:
+        staged["r_entry"] = leg(r_entry_leg, ed, chrom_off, start, end, test, ref, S, max(2, args.steps // 3), args.fit, phi, p)
     workflow = None
     if args.workflow_reps > 0 and plain and args.fit and not args.fused and S >= 64 and (world == 1 or use_pg):
         workflow = leg(workflow_leg, ed, torch, plan, test, start, end, E, S, args.workflow_reps, EMIT_MODES[args.emit_mode], world, rank, eddist)

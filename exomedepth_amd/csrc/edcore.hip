@@ -2672,21 +2672,14 @@ static int batch_run_impl(ed_batch* b, const int32_t* d_test, const int32_t* d_r
       if (const char* e = ed_knob("ED_SM_NSPLIT")) { if (atoi(e) > 0) nsplit = atoi(e); }
       nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(nsplit, n / 32));
       const int64_t nwg = ((S + 7) / 8) * 8 * nsplit;
-      const unsigned ntw = (unsigned)std::min<int64_t>(nwg, 1024);      // the tail samples' persistent grid (returns at once when the slab has none)
-      if (cl1 && cb == 2) {
+      if (cl1 && cb == 2)
         hipLaunchKernelGGL(k_emit_tab_sm<2>, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, d_test, d_ref, b->d_tdims, b->d_tabs, b->tab_stride,
-                           b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_twins);
-        if (b->tab_tails)
-          hipLaunchKernelGGL(k_emit_tail_sm<2>, dim3(ntw), dim3(kSmBlock), 0, st, d_test, d_ref, b->d_tdims, b->d_twins, b->d_tlg0, b->d_consts, b->d_tabs, b->tab_stride,
-                             b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_notab + (S + 1));
-      } else {
+                           b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_twins, b->d_tlg0,
+                           b->d_consts);
+      else
         hipLaunchKernelGGL(k_emit_tab_sm<4>, dim3((unsigned)nwg), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_tabs, b->tab_stride,
-                           b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_twins);
-        if (b->tab_tails)
-          hipLaunchKernelGGL(k_emit_tail_sm<4>, dim3(ntw), dim3(kSmBlock), 0, st, cl1 ? d_test : b->d_test_sm, cl1 ? d_ref : b->d_ref_sm, b->d_tdims, b->d_twins, b->d_tlg0,
-                             b->d_consts, b->d_tabs, b->tab_stride, b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n,
-                             b->cold_cap, b->d_notab + (S + 1));
-      }
+                           b->d_blk_sm, b->nblk_sm, base, n, nsplit, S, E, b->Epad, b->d_loglik_sm, b->d_cold_list, b->d_cold_n, b->cold_cap, b->d_twins, b->d_tlg0,
+                           b->d_consts);
       return;
     }
     const uint32_t nsb = (uint32_t)((S + b->tab_tw - 1) / b->tab_tw);

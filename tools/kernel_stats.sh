@@ -1,5 +1,5 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/ks
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -o ks -- python bench.py --steps 5 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 "$@" > gpurun_out/ks/log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -o ks -- python bench.py --steps 5 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --regimes 0 --dropin 0 --regimes 0 --dropin 0 "$@" > gpurun_out/ks/log 2>&1
 python - <<'PY'
 import csv
 rows=list(csv.reader(open('gpurun_out/ks/ks_kernel_stats.csv')))

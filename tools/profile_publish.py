@@ -8,7 +8,7 @@ src = os.path.join("gpurun_out", tag)
 n = 0
 for f in sorted(glob.glob(os.path.join(src, "*"))):
     b = os.path.basename(f)
-    if b in ("kernel_stats.csv", "wf_kernel_stats.csv", "rc_gram.json", "meta.json", "bench_line.json") or (b.startswith("pmc_") and b.endswith(".csv")) or b.startswith("bench_") and b.endswith(".json"):
+    if b in ("kernel_stats.csv", "kernel_stats_timed.csv", "wf_kernel_stats.csv", "rc_gram.json", "meta.json", "bench_line.json", "bench_line_wf.json") or (b.startswith("pmc_") and b.endswith(".csv")) or b.startswith("bench_") and b.endswith(".json"):
         shutil.copy(f, os.path.join("profiles", "%s_%s" % (tag, b)))
         n += 1
 print("published %d files as profiles/%s_*" % (n, tag))

@@ -9,7 +9,7 @@ OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 EXTRA="${@:2}"     # further bench.py flags (e.g. --emit-mode strict)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python bench.py --steps 5 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 $EXTRA > $OUT/bench_ks.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python bench.py --steps 5 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --regimes 0 --dropin 0 --regimes 0 --dropin 0 $EXTRA > $OUT/bench_ks.log 2>&1
 grep -h '^{' $OUT/bench_ks.log > $OUT/bench_line.json
 python - "$OUT" <<'PY'
 import csv, sys
@@ -26,13 +26,13 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LD
   [ "$N" = "SQ_WAVES" ] && N=SQ
   [ "$N" = "TCC_HIT_sum" ] && N=TCC
   [ "$N" = "SQ_LDS_BANK_CONFLICT" ] && N=LDS
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o pmc_$N -- python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 $EXTRA > $OUT/pmc_$N.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o pmc_$N -- python bench.py --steps 2 --warmup 1 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --regimes 0 --dropin 0 --regimes 0 --dropin 0 $EXTRA > $OUT/pmc_$N.log 2>&1
   python tools/pmc_summary.py $OUT/pmc_${N}_counter_collection.csv > $OUT/pmc_$N.csv
   rm -f $OUT/pmc_${N}_counter_collection.csv $OUT/pmc_${N}_kernel_trace.csv
 done
 # ---- the workflow leg (extra.workflow: upload -> reference sets for every sample -> calls): its kernels (k_rc_*, k_fit_accum_batched, ...)
 #      in a kernel trace of their own and one PMC pass (MFMA work of k_rc_gram) ----
-WF="--steps 1 --warmup 0 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --strict-steps 0 --workflow-reps 2"
+WF="--steps 1 --warmup 0 --cpu-samples 0 --kernel-alone 0 --verify-columns 0 --fit-concordance 0 --config1-steps 0 --stage-inputs 0 --strict-steps 0 --regimes 0 --dropin 0 --workflow-reps 2"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o wf -- python bench.py $WF $EXTRA > $OUT/bench_wf.log 2>&1
 grep -h '^{' $OUT/bench_wf.log > $OUT/bench_line_wf.json
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT -o pmc_WF -- python bench.py $WF $EXTRA > $OUT/pmc_WF.log 2>&1

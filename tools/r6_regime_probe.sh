@@ -1,10 +1,10 @@
 set -x
 mkdir -p gpurun_out/r6a
 for d in 25 100 400 1600; do
-  python bench.py --depth $d --steps 10 --warmup 2 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --config1-steps 0 --cpu-samples 0 --fit-concordance 0 --verify-columns 2 > gpurun_out/r6a/depth_$d.json 2> gpurun_out/r6a/depth_$d.err
+  python bench.py --depth $d --steps 10 --warmup 2 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --regimes 0 --dropin 0 --config1-steps 0 --cpu-samples 0 --fit-concordance 0 --verify-columns 2 > gpurun_out/r6a/depth_$d.json 2> gpurun_out/r6a/depth_$d.err
 done
 for s in 64 256; do
-  python bench.py --samples $s --steps 10 --warmup 2 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --config1-steps 0 --cpu-samples 0 --fit-concordance 0 --verify-columns 2 > gpurun_out/r6a/S_$s.json 2> gpurun_out/r6a/S_$s.err
+  python bench.py --samples $s --steps 10 --warmup 2 --stage-inputs 0 --workflow-reps 0 --strict-steps 0 --regimes 0 --dropin 0 --config1-steps 0 --cpu-samples 0 --fit-concordance 0 --verify-columns 2 > gpurun_out/r6a/S_$s.json 2> gpurun_out/r6a/S_$s.err
 done
 python - <<'PY'
 import json,glob
