@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--fit", type=int, default=1, help="1: (phi, expected) fitted on the device (BASELINE configs[2]); 0: the generator's (configs[1])")
     ap.add_argument("--deep", action="store_true")
     ap.add_argument("--counts-bits", type=int, default=32, help="16: the device counts as uint16 (ed_batch_set_counts_bits; tables mode)")
+    ap.add_argument("--depth", type=float, default=100.0, help="median reads per exon and test sample of the synthetic counts (from ~250 on the samples are tail samples: "
+                    "Stirling's series beyond the LDS windows, DESIGN.md 4.13)")
     ap.add_argument("--seed", type=int, default=20250621)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--margins", action="store_true", help="also: for every decision ON the reference's Viterbi path (the state the path is in at an "
@@ -38,7 +40,7 @@ def main():
 
     S, E, C = args.samples, args.exons, 24
     chrom_off, start, end = synth.exon_design(E, C, args.seed)
-    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, args.seed)
+    test, ref, p, phi, _ = synth.counts_numpy(chrom_off, S, args.seed, mean_depth=args.depth)
     if args.deep:
         rng = np.random.default_rng(args.seed + 1)
         dt = torch.from_numpy(test).cuda()
@@ -73,6 +75,7 @@ def main():
         b.run(dt, dr, phi, p)
         n_unconv = 0
     tstats = b.table_stats() if mode else None
+    n_tail = sum(1 for s in range(S) if b.table_windows(s)[3]) if mode == 2 else None
     n_tab = sum(1 for s in range(S) if b.table_dims(s)[0] > 0) if mode else None
     path, calls = b.path(), b.calls()
     ll = b.loglik()
@@ -121,7 +124,7 @@ def main():
            "reference_call_rows": sum(r[6] for r in res), "discordant_call_rows": sum(r[5] for r in res),
            "n_gsl_errors": int(nerr), "fit_unconverged": n_unconv,
            "expected_range": [float(np.min(p)), float(np.max(p))], "phi_range": [float(np.min(phi)), float(np.max(phi))],
-           "table_stats": tstats, "samples_on_tables": n_tab,
+           "table_stats": tstats, "samples_on_tables": n_tab, "tail_samples": n_tail, "depth": args.depth,
            "cpu_threads": nthr, "cpu_seconds_wall": time.time() - t0}
     if args.margins:
         mgs = [r[8] for r in res]
