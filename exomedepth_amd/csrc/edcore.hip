@@ -29,6 +29,8 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1387,6 +1389,9 @@ __global__ void k_fit_skip_prefixes(const double* __restrict__ eta, int* __restr
   skip_from[j] = from;
 }
 
+#ifndef ED_FIT_PACK_EARLY
+#define ED_FIT_PACK_EARLY 1
+#endif
 #ifndef ED_FIT_PRE
 #define ED_FIT_PRE 8      // cells of a column requested ahead of the one being consumed (round 5: 4 -> 8)
 #endif
@@ -3019,9 +3024,20 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   // coarse Newton steps on every 16th exon, then full passes until the step is below tolerance
   const int coarse = (E >= 8192) ? kFitCoarsePasses : 0;   // a stride-16 subset below ~500 exons is too noisy to help
   const int cstride = 16;                   // (8 / 4 / 2 measured on the cohort reference sets' 10 000-row fit: 9.9 / 11.1 / 12.3 ms against 9.6)
+  // Prefixes closed before the first pass (k_fit_skip_prefixes) are lanes that idle through every pass: the columns that iterate are packed from the
+  // start then (round 6), and again before each of the first full passes as columns converge.  Which slot a column takes does not show in its sums.
+  const bool can_pack = S >= 4096 && w.colmap;
+  const bool pack_early = can_pack && skip_K > 0 && tmod > 0 && d_skip_from && ED_FIT_PACK_EARLY;
+  auto compact = [&]() {
+    (void)hipMemsetAsync(w.n_map, 0, 4, st);
+    hipLaunchKernelGGL(k_fit_compact, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, w.done, S, w.colmap, w.n_map);
+  };
+  if (pack_early) compact();
   for (int it = 0; it < coarse; ++it) {
-    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, cstride, w.eta, w.lam, w.done, w.partial, tmod);
-    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 0);
+    hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, cstride, w.eta, w.lam, w.done, w.partial, tmod,
+                       pack_early ? w.colmap : (const int32_t*)nullptr, pack_early ? w.n_map : (const int*)nullptr);
+    hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, 1e-6, 0,
+                       pack_early ? w.colmap : (const int32_t*)nullptr, pack_early ? w.n_map : (const int*)nullptr);
   }
   // (round 5: two passes on every 4th exon between the coarse and the full ones were tried -- 9.2 -> 10.0 ms for the cohort reference sets'
   //  32 768 columns: the full passes needed are the same three, the medium ones came on top)
@@ -3031,11 +3047,8 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
   const double step_tol = (tcs == 0 || tmod > 0) ? kFitStepTol : 1e-6;
   for (int it = 0; it < 10; ++it) {   // converged columns skip their work; typically 3 passes do something
     // from the fourth pass on: the columns still iterating packed into the first waves (k_fit_compact), many columns only
-    const bool packed = it >= 3 && S >= 4096 && w.colmap;
-    if (it == 3 && packed) {
-      HIP_TRY(hipMemsetAsync(w.n_map, 0, 4, st));
-      hipLaunchKernelGGL(k_fit_compact, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, w.done, S, w.colmap, w.n_map);
-    }
+    const bool packed = can_pack && (it >= 3 || pack_early);
+    if (packed && (it == 3 || (pack_early && it >= 1 && it < 3))) compact();
     hipLaunchKernelGGL(k_fit_accum, grid, block, 0, st, d_test, trs, tcs, d_ref, rrs, E, S, 1, w.eta, w.lam, w.done, w.partial, tmod,
                        packed ? w.colmap : (const int32_t*)nullptr, packed ? w.n_map : (const int*)nullptr);
     hipLaunchKernelGGL(k_fit_update, gr, br, 0, st, w.partial, nch, S, w.eta, w.lam, w.done, step_tol, 1,

@@ -91,6 +91,47 @@ def test_prefix_shares_merge_to_the_whole(edlib):
             assert np.isnan(w["expected_BF"]).any()      # the early exit did trigger
 
 
+
+def test_get_power_betabinom_walk_against_mpmath(edlib):
+    """The default case walks the two mass functions (k_rs_power_walk, round 6: step ratios, one logarithm per x) instead of three lnbeta per
+    term.  Against 50-digit arithmetic at every tile boundary of the walk (256 values per tile), on a near-null alternative (where the sum is
+    a cancellation of terms of both signs: the term-by-term form keeps 1e-8 there, the walk 1e-10) and against the term-by-term checker on a
+    spread of parameters; as phi -> 0 the walk approaches the binomial case (where differences of lnbeta values of order 1 / phi have no digits left)."""
+    import mpmath as mp
+    from oracle import refset_oracle as ro
+    mp.mp.dps = 40
+
+    def exact(size, phi, p, alt):
+        phi, p, alt = mp.mpf(float(phi)), mp.mpf(float(p)), mp.mpf(float(alt))
+        a, b, aa, ab = p * (1 - phi) / phi, (1 - p) * (1 - phi) / phi, alt * (1 - phi) / phi, (1 - alt) * (1 - phi) / phi
+        lb = lambda x, y: mp.loggamma(x) + mp.loggamma(y) - mp.loggamma(x + y)
+        tot = mp.mpf(0)
+        for x in range(int(size) + 1):
+            la = lb(aa + x, ab + size - x) - lb(aa, ab)
+            tot += mp.e ** (-mp.log(size + 1) - lb(size - x + 1, x + 1) + la) * (la - (lb(a + x, b + size - x) - lb(a, b)))
+        return float(tot * mp.log10(mp.e))
+
+    cases = [(0, .05, .3, .2), (1, .05, .3, .2), (3, .2, .5, .4), (4, .2, .5, .4), (5, .2, .5, .4), (255, .01, .1, .0526), (256, .01, .1, .0526),
+             (257, .01, .1, .0526), (511, .003, .11, .06), (512, .003, .11, .06), (1025, .02, .4, .25), (2100, 1e-6, .02, .0101),
+             (1500, 0.037713, 0.294922, 0.297696), (700, .5, .9, .05)]
+    size, phi, p, alt = (np.array(c, dtype=float) for c in zip(*cases))
+    got = edlib.get_power_betabinom(size, phi, p, alt)
+    want = np.array([exact(*c) for c in cases])
+    assert np.allclose(got, want, rtol=2e-10, atol=1e-15), (got, want)
+    rng = np.random.default_rng(3)
+    n = 300
+    size = rng.integers(0, 6000, n).astype(float)
+    phi = 10.0 ** rng.uniform(-6, -0.3, n)
+    p = rng.uniform(0.01, 0.9, n)
+    alt = np.where(rng.random(n) < 0.5, (p / (1 - p) * 0.5) / (1 + p / (1 - p) * 0.5), rng.uniform(0.01, 0.9, n))
+    got = edlib.get_power_betabinom(size, phi, p, alt)
+    exp = np.array([ro.get_power_betabinom(int(s), f, q, a) for s, f, q, a in zip(size, phi, p, alt)])
+    assert np.allclose(got, exp, rtol=1e-8, atol=1e-11)
+    tiny = edlib.get_power_betabinom([300.0, 300.0], [1e-70, 1e-9], [.2, .2], [.1, .1])
+    binom = float(np.ravel(edlib.get_power_betabinom([300.0], [.5], [.2], [.1], theory=True))[0])
+    assert np.isfinite(tiny).all() and abs(tiny[0] - binom) < 1e-6 * binom and abs(tiny[1] - binom) < 1e-5 * binom
+
+
 def test_get_power_betabinom_standalone(edlib):
     """reference R/tools.R:128-166, default mode, incl. its two documented examples (my.alt.p = my.p gives 0)."""
     from oracle import refset_oracle as ro
