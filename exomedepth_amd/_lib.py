@@ -97,6 +97,7 @@ SYMBOLS = [
     ("ed_cohort_select_reference_sets_sm", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     ("ed_cohort_select_reference_sets_host", C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     ("ed_release_scratch", C.c_int, []),
+    ("ed_refcohort_last_path", C.c_int, [C.POINTER(C.c_int64)]),
     ("ed_refset_finalize", C.c_int, [_vp, _i64, C.POINTER(_i32)]),
     ("ed_refset_thin_positions", C.c_int, [_i64, _i64, _vp, _i64, C.POINTER(_i64)]),
     ("ed_get_power_betabinom", C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),

@@ -1489,15 +1489,17 @@ __device__ __forceinline__ void fit_newton_step(const double (&tot)[kFitQ], doub
   const double p = 1.0 / (1.0 + ed_pexp(-eta_v));
   const double q = 1.0 - p;
   const double a = th * p, b = th * q;
-  double pa, qa, pb, qb, pt, qt;
-  edfit::digamma_trigamma(a, pa, qa);
-  edfit::digamma_trigamma(b, pb, qb);
-  edfit::digamma_trigamma(th, pt, qt);
-  ga -= cnt * (pa - pt);
-  gb -= cnt * (pb - pt);
-  haa -= cnt * (qa - qt);
-  hab += cnt * qt;
-  hbb -= cnt * (qb - qt);
+  if (cnt != 0.0) {                                // (0: the caller's sums already hold the constant terms -- the histogram forms)
+    double pa, qa, pb, qb, pt, qt;
+    edfit::digamma_trigamma(a, pa, qa);
+    edfit::digamma_trigamma(b, pb, qb);
+    edfit::digamma_trigamma(th, pt, qt);
+    ga -= cnt * (pa - pt);
+    gb -= cnt * (pb - pt);
+    haa -= cnt * (qa - qt);
+    hab += cnt * qt;
+    hbb -= cnt * (qb - qt);
+  }
   const double ae = a * q, be = -b * p;          // d a / d eta, d b / d eta
   const double g_e = ga * ae + gb * be;
   const double g_l = ga * a + gb * b;

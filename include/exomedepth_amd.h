@@ -457,6 +457,12 @@ int ed_cohort_select_reference_sets_sm(const int32_t* d_counts, int64_t n_bins, 
 /* ed_cohort_select_reference_sets keeps its device scratch (about 1.5 GB at 10 000 selected bins x 1024 samples) between calls;
  * this returns it to the device. */
 int ed_release_scratch(void);
+/* How the last ed_cohort_select_reference_sets* call of this process formed its cumulative references' statistics (tests, diagnostics): out = {chunks
+ * served by the column-major kernel (csrc/edrefcohort.inc: k_rc_column), chunks served by the row-major kernels (more than 65 535 selected bins, or counts
+ * the column kernel's bins could not hold), columns that had counts beyond those bins, the most Newton iterations a column took, the geometry that
+ * served the last chunk (1: 10 240 bins, 2: 34 816 bins, 0: the row-major kernels)}.  The two forms follow R/optimize_reference_set.R:114-128 alike;
+ * they differ in the rounding of the fits. */
+int ed_refcohort_last_path(int64_t out[5]);
 /* ... on host data in R's layout: counts the n_bins x n_samples integer matrix, column-major; reference_out_colmajor (optional)
  * receives the aggregate reference in the same layout.  The other arguments as above. */
 int ed_cohort_select_reference_sets_host(const int32_t* counts_colmajor, int64_t n_bins, int64_t n_samples, const double* bin_length,
