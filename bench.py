@@ -323,11 +323,15 @@ def r_entry_leg(ed, chrom_off, start, end, test, ref, S, steps, fit, phi, p):
     for name, narrow in (("narrowed_while_staged", 1), ("int32_on_link_and_device", 0)):
         m = ed.MultiDevice(chrom_off, start, end, 256, devices=[0], emit_mode=2, counts_layout=1, host_narrow=narrow)
         res = m.run_host(th, rh, 1, **par)
+        each = []
         t0 = time.perf_counter()
         for _ in range(steps):
+            t1 = time.perf_counter()
             res = m.run_host(th, rh, 1, **par)
+            each.append((time.perf_counter() - t1) * 1e3)
         el = time.perf_counter() - t0
-        out[name] = {"ms_per_cohort": el / steps * 1e3, "value": float(th.size) * steps / el, "n_calls": len(res["calls"]),
+        # (run to run the leg moves by 20 %: where the pageable pages and the staging threads sit relative to the device's NUMA node; mean and best)
+        out[name] = {"ms_per_cohort": el / steps * 1e3, "ms_best": min(each), "value": float(th.size) * steps / el, "n_calls": len(res["calls"]),
                      "link_GBps": 2.0 * th.size * (2 if narrow else 4) * steps / el / 1e9}
         m.close()
     out["ratio"] = out["narrowed_while_staged"]["ms_per_cohort"] / out["int32_on_link_and_device"]["ms_per_cohort"]
@@ -447,6 +451,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
         t3 = time.perf_counter()
         tstats = b.table_stats() if emit_mode else None
         n_chosen = float(rs["n_chosen"].mean())
+        rs_path = ed.refcohort_last_path()            # which form served the cumulative references (k_rc_column's geometry, or the row-major kernels)
         checksum = int(np.sum((rs["choice"].astype(np.int64) + 1) * (np.arange(rs["choice"].shape[1], dtype=np.int64) + 1)[None, :]))
         if rep > 0:                                   # (the first repetition allocates)
             for k, v in zip(("upload_ms", "reference_sets_ms", "calls_ms", "total_ms"), (t1 - t0, t2 - t1, t3 - t2, t3 - t0)):
@@ -502,7 +507,7 @@ def workflow_leg(ed, torch, plan, test, start, end, E, S, reps, emit_mode=0, wor
                         "when the calls run in the sample-major table mode on one rank) -> fit + emissions + Viterbi + calls; "
                         "stages one after the other (one cohort, nothing to overlap with), median of %d" % (S, E, reps),
             **med, "value": E * S * world / (med["total_ms"] * 1e-3), "unit": "exons*samples/s", "references_chosen_mean": n_chosen, "n_calls": n_calls, "table_stats": tstats,
-            "ranks": world, "choice_checksum_rank0": checksum, "back_to_back": back_to_back,
+            "ranks": world, "choice_checksum_rank0": checksum, "reference_sets_form": rs_path, "back_to_back": back_to_back,
             "sharding": (None if not sharded else "every rank: its own %d columns as tests, all %d as candidates (one all_gather of the count slabs); "
                                                   "times and counts are rank 0's" % (S, S * world))}
 

@@ -1097,10 +1097,10 @@ def select_reference_set(test_counts, reference_counts, bin_length=None, n_bins_
 
 def refcohort_last_path():
     """ed_refcohort_last_path: how the last cohort_select_reference_sets call formed the statistics of its cumulative references --
-    dict(chunks_by_columns, chunks_row_major, columns_beyond_bins, max_newton_iterations, geometry)."""
+    dict(chunks_by_columns, chunks_row_major, columns_beyond_bins, max_newton_iterations, columns_large_geometry)."""
     out = (C.c_int64 * 5)()
     check(lib().ed_refcohort_last_path(out))
-    return dict(zip(("chunks_by_columns", "chunks_row_major", "columns_beyond_bins", "max_newton_iterations", "geometry"), (int(v) for v in out)))
+    return dict(zip(("chunks_by_columns", "chunks_row_major", "columns_beyond_bins", "max_newton_iterations", "columns_large_geometry"), (int(v) for v in out)))
 
 
 def cohort_select_reference_sets(counts, bin_length=None, n_bins_reduced=0, max_refs=32, want_reference=True, want_correlations=False,

@@ -459,9 +459,9 @@ int ed_cohort_select_reference_sets_sm(const int32_t* d_counts, int64_t n_bins, 
 int ed_release_scratch(void);
 /* How the last ed_cohort_select_reference_sets* call of this process formed its cumulative references' statistics (tests, diagnostics): out = {chunks
  * served by the column-major kernel (csrc/edrefcohort.inc: k_rc_column), chunks served by the row-major kernels (more than 65 535 selected bins, or counts
- * the column kernel's bins could not hold), columns that had counts beyond those bins, the most Newton iterations a column took, the geometry that
- * served the last chunk (1: 10 240 bins, 2: 34 816 bins, 0: the row-major kernels)}.  The two forms follow R/optimize_reference_set.R:114-128 alike;
- * they differ in the rounding of the fits. */
+ * beyond the reach of the column kernel's large bins), columns that kept counts beyond their bins as values, the most Newton iterations a column took,
+ * columns served by the large geometry (34 816 bins; the others: 10 240)}.  The two forms follow R/optimize_reference_set.R:114-128 alike; they differ in
+ * the rounding of the fits. */
 int ed_refcohort_last_path(int64_t out[5]);
 /* ... on host data in R's layout: counts the n_bins x n_samples integer matrix, column-major; reference_out_colmajor (optional)
  * receives the aggregate reference in the same layout.  The other arguments as above. */

@@ -69,23 +69,23 @@ def _same_selection(a, b, stats_tol):
         assert np.allclose(x, y, rtol=tol, atol=0), (f, float(np.max(np.abs(x - y) / np.abs(y))))
 
 
-@pytest.mark.parametrize("depth,geometry", [(90.0, 1), (140.0, 1), (250.0, 2), (450.0, 2), (4000.0, 0)])
-def test_column_major_and_row_major_forms_agree(edlib, monkeypatch, depth, geometry):
+@pytest.mark.parametrize("depth", [90.0, 140.0, 250.0, 450.0, 4000.0])
+def test_column_major_and_row_major_forms_agree(edlib, monkeypatch, depth):
     """The chunk loop has two forms (csrc/edrefcohort.inc): one workgroup per cumulative reference on the column's count histograms (k_rc_column:
-    the fit on tail counts, the median and RatioSd from the same bins; two geometries), and the row-major kernels of rounds 2-5.  Same choices, the same
-    medians, the other statistics to the fits' rounding -- at depths the small bins hold (with and without values beyond them, which are kept as sorted
-    values), at depths that take the large bins, and at one that is left to the row-major kernels; and with the geometry forced the wrong way: a column
-    with more values beyond the bins than are kept raises the flag and the next form takes the chunk."""
+    the fit on tail counts, the median and RatioSd from the same bins; two geometries, chosen per column from its mean depth, the small one handing
+    on what it cannot hold), and the row-major kernels of rounds 2-5.  Same choices, the same medians, the other statistics to the fits' rounding --
+    at depths where the small bins hold every column (with and without values beyond them, which are kept as sorted values), where the deep
+    prefixes take the large bins, and where the chunk is left to the row-major kernels; and with every column forced through one geometry first."""
     counts, bl = _cohort(E=9000, S=48, seed=21, depth=depth)
     got = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=32, want_reference=False)
     path = edlib.refcohort_last_path()
-    assert path["geometry"] == geometry, path
-    assert (path["chunks_by_columns"], path["chunks_row_major"]) == ((1, 0) if geometry else (0, 1))
+    by_columns = depth < 4000.0
+    assert (path["chunks_by_columns"], path["chunks_row_major"]) == ((1, 0) if by_columns else (0, 1)), path
     if depth == 90.0:
-        assert path["columns_beyond_bins"] == 0
-    if depth in (140.0, 450.0):
-        assert path["columns_beyond_bins"] > 0
-    if geometry:
+        assert path["columns_beyond_bins"] == 0 and path["columns_large_geometry"] == 0, path
+    if depth >= 250.0 and by_columns:
+        assert path["columns_large_geometry"] > 0, path
+    if by_columns:
         assert 0 < path["max_newton_iterations"] < 30
     monkeypatch.setenv("ED_REFCOHORT_ROWMAJOR", "1")
     ref = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=32, want_reference=False)
@@ -95,17 +95,23 @@ def test_column_major_and_row_major_forms_agree(edlib, monkeypatch, depth, geome
     again = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=32, want_reference=False)       # the same bits run to run
     for f in ("phi", "mean_p", "ratio_sd", "expected_BF", "median_depth"):
         assert np.array_equal(got["summary.stats"][f], again["summary.stats"][f], equal_nan=True), f
-    if depth in (250.0, 4000.0):          # the small geometry forced on data it cannot hold: the flag, then the next form -- the same answer
+    if depth in (140.0, 250.0, 4000.0):   # every column through the small geometry first: what it cannot hold is handed on (and at 4 000 the large one gives up too)
         monkeypatch.setenv("ED_REFCOHORT_GEOMETRY", "1")
         forced = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=32, want_reference=False)
         p2 = edlib.refcohort_last_path()
         monkeypatch.delenv("ED_REFCOHORT_GEOMETRY")
-        assert p2["geometry"] == (2 if depth == 250.0 else 0), p2
+        if depth == 140.0:
+            assert p2["chunks_by_columns"] == 1 and p2["columns_beyond_bins"] > 0, p2      # values beyond the small bins, kept in the lists
+        if depth == 250.0:
+            assert p2["chunks_by_columns"] == 1 and p2["columns_large_geometry"] > 0, p2
+        if depth == 4000.0:
+            assert p2["chunks_row_major"] == 1, p2
         _same_selection(forced, ref, 3e-8)
     if depth == 90.0:                     # the large geometry on shallow data: the same fits from other bins
         monkeypatch.setenv("ED_REFCOHORT_GEOMETRY", "2")
         forced = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=32, want_reference=False)
-        assert edlib.refcohort_last_path()["geometry"] == 2
+        p2 = edlib.refcohort_last_path()
+        assert p2["columns_large_geometry"] > 1000 and p2["chunks_by_columns"] == 1, p2
         monkeypatch.delenv("ED_REFCOHORT_GEOMETRY")
         _same_selection(forced, got, 1e-11)
 
@@ -119,7 +125,7 @@ def test_column_form_against_the_long_double_mle(edlib, depth):
     from oracle import refset_oracle as ro
     counts, bl = _cohort(E=9000, S=48, seed=21, depth=depth)
     res = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=32, want_reference=False)
-    assert edlib.refcohort_last_path()["geometry"] == (1 if depth == 90.0 else 2)
+    assert (edlib.refcohort_last_path()["columns_large_geometry"] > 0) == (depth == 250.0)
     for t in (0, 17, 40):
         others = np.delete(np.arange(48), t)
         one = ro.select_reference_set_lean(counts[:, t], np.ascontiguousarray(counts[:, others]), bl, 0)
