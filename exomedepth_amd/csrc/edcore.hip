@@ -1689,6 +1689,8 @@ __global__ void k_eval_sf(int which, int64_t n, const double* __restrict__ x, co
 
 }  // namespace
 
+#include "edfit_col.inc"
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------

@@ -140,6 +140,22 @@ def test_column_form_against_the_long_double_mle(edlib, depth):
             assert np.allclose(a[m], b[m], rtol=tol, atol=0), (t, f, float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))))
 
 
+def test_a_negative_count_leaves_the_chunk_to_the_row_major_kernels(edlib, monkeypatch):
+    """not a count: the column form does not interpret it (its bins are indexed by the counts) -- the columns that hold one raise the flag, and the
+    chunk gets what the row-major kernels' per-cell arithmetic makes of it, as before"""
+    counts, bl = _cohort(E=6000, S=24, seed=5)
+    counts[counts.sum(axis=1).argsort()[3000], 7] = -1           # in a bin the selection keeps (total near the median)
+    got = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=23, want_reference=False)
+    path = edlib.refcohort_last_path()
+    assert path["chunks_row_major"] == 1 and path["chunks_by_columns"] == 0, path
+    monkeypatch.setenv("ED_REFCOHORT_ROWMAJOR", "1")
+    ref = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=23, want_reference=False)
+    monkeypatch.delenv("ED_REFCOHORT_ROWMAJOR")
+    assert np.array_equal(got["choice"], ref["choice"])
+    for f in ("phi", "mean_p", "ratio_sd", "expected_BF", "median_depth"):
+        assert np.array_equal(got["summary.stats"][f], ref["summary.stats"][f], equal_nan=True), f
+
+
 def test_more_bins_than_the_column_form_takes(edlib):
     """more than 65 535 selected bins: 16-bit tail counts do not hold them -- the row-major kernels, as before"""
     counts, bl = _cohort(E=110_000, S=12, seed=4, depth=60.0)
