@@ -1,7 +1,7 @@
 # timeline of the workflow leg's last repetition: kernel, start (ms from the first kernel of the repetition), duration, gap to the previous kernel's end
 export TMPDIR=/tmp; mkdir -p gpurun_out/wftl
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/wftl -o wf -- python bench.py --steps 1 --warmup 0 --stage-inputs 0 --strict-steps 0 --config1-steps 0 --cpu-samples 0 --fit-concordance 0 --verify-columns 0 --kernel-alone 0 --regimes 0 --dropin 0 --workflow-reps 2 > gpurun_out/wftl/log 2>&1
-python - <<'PY' > gpurun_out/r06_wf_timeline.txt
+python - <<'PY' > gpurun_out/wf_timeline.txt
 import csv
 rows = list(csv.DictReader(open('gpurun_out/wftl/wf_kernel_trace.csv')))
 ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')) for r in rows))
