@@ -156,6 +156,26 @@ def test_a_negative_count_leaves_the_chunk_to_the_row_major_kernels(edlib, monke
         assert np.array_equal(got["summary.stats"][f], ref["summary.stats"][f], equal_nan=True), f
 
 
+def test_a_hand_over_the_host_did_not_predict(edlib, monkeypatch):
+    """The host gives a column its geometry from its MEAN depth; a cohort whose bins come in two depths (most shallow, one in twenty 25 times deeper -- still
+    below the 90 % quantile of the totals, so selected) has small means and thousands of cells beyond the small bins: the small geometry's workgroups hand
+    such columns on, and the large launch, which was not issued beside them, is issued after all.  Same answer as the row-major kernels."""
+    rng = np.random.default_rng(3)
+    E, S = 40000, 32
+    deep = rng.random(E) < 0.14
+    lam = np.where(deep, 1000.0, 40.0) * rng.lognormal(0, 0.15, E)
+    sf = rng.lognormal(0, 0.2, S)
+    counts = rng.poisson(lam[:, None] * sf[None, :] * np.exp(rng.normal(0, 0.08, (E, S)))).astype(np.int32)
+    bl = rng.integers(80, 600, E).astype(float)
+    got = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=31, want_reference=False)
+    path = edlib.refcohort_last_path()
+    assert path["chunks_by_columns"] == 1 and path["columns_large_geometry"] > 0, path
+    monkeypatch.setenv("ED_REFCOHORT_ROWMAJOR", "1")
+    ref = edlib.cohort_select_reference_sets(counts, bl, 0, max_refs=31, want_reference=False)
+    monkeypatch.delenv("ED_REFCOHORT_ROWMAJOR")
+    _same_selection(got, ref, 3e-8)
+
+
 def test_more_bins_than_the_column_form_takes(edlib):
     """more than 65 535 selected bins: 16-bit tail counts do not hold them -- the row-major kernels, as before"""
     counts, bl = _cohort(E=110_000, S=12, seed=4, depth=60.0)
