@@ -81,6 +81,9 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             "sgprasm": ["-DED_PM_FMA_K_SGPR_OPERAND"],
             # k_fit_hist of the shallow geometry with 4 samples per workgroup: half the LDS, emission workgroups fit beside it
             "fitlight": ["-DED_HG8_WG=4"],
+            # every automatic variable starts from a bit pattern (0xAA...) instead of whatever the register or stack slot held: a read of an uninitialised
+            # variable shows up as a wrong (and reproducible) result instead of a run-to-run difference -- host and device code
+            "autoinit": ["-ftrivial-auto-var-init=pattern"],
             # host code under the sanitizers (device code is left alone: -fno-gpu-sanitize); tools/sanitize.sh
             # (no -shared-libsan: the runtime is whatever tools/sanitize.sh preloads -- gcc's stock libasan / libtsan; ROCm's own
             # ASan runtime intercepts hsa_amd_memory_pool_allocate for DEVICE instrumentation and fails on a plain process)
