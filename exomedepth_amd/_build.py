@@ -84,6 +84,9 @@ VARIANTS = {"coldinline": ["-DED_COLD_INLINE"],
             # every automatic variable starts from a bit pattern (0xAA...) instead of whatever the register or stack slot held: a read of an uninitialised
             # variable shows up as a wrong (and reproducible) result instead of a run-to-run difference -- host and device code
             "autoinit": ["-ftrivial-auto-var-init=pattern"],
+            # k_fit_hnewton's per-cell path with the short digamma series (irreproducible fits), alone and with pattern-initialised variables
+            "hnshort": ["-DED_HN_SHORT_SERIES"], "hnshortinit": ["-DED_HN_SHORT_SERIES", "-ftrivial-auto-var-init=pattern"],
+            "hnshortplain": ["-DED_HN_SHORT_SERIES", "-DED_FIT_PLAIN_FMA"], "fitplain": ["-DED_FIT_PLAIN_FMA"],
             # host code under the sanitizers (device code is left alone: -fno-gpu-sanitize); tools/sanitize.sh
             # (no -shared-libsan: the runtime is whatever tools/sanitize.sh preloads -- gcc's stock libasan / libtsan; ROCm's own
             # ASan runtime intercepts hsa_amd_memory_pool_allocate for DEVICE instrumentation and fails on a plain process)

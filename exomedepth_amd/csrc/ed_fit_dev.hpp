@@ -15,6 +15,14 @@
 
 namespace edfit {
 
+// Horner step of the fit's series.  ed_pm_fma_k (ed_pmath.h) pins its coefficient to a fixed scalar register pair through inline assembly -- the strict
+// emission kernels' register budget is built on that; ED_FIT_PLAIN_FMA (diagnostic builds) leaves the coefficient to the compiler here.
+#ifdef ED_FIT_PLAIN_FMA
+#define EDFIT_FMA_K(a, b, k) __builtin_fma((a), (b), (k))
+#else
+#define EDFIT_FMA_K(a, b, k) ed_pm_fma_k((a), (b), (k))
+#endif
+
 // Reciprocal and logarithm for the fit.  Nothing here has to match the checker bit for bit (the fit is
 // compared by tolerance), so the reciprocal is v_rcp_f64 + two Newton steps (~1 ulp) instead of an IEEE
 // division, and the logarithm is ed_plog's algorithm on top of that reciprocal.
@@ -39,7 +47,7 @@ __device__ __forceinline__ double flog(double x)   // x normal, positive, finite
   const double z = s * s;
   double g = c[ED_PM_LOG_NC - 1];
 #pragma unroll
-  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = ed_pm_fma_k(g, z, c[i]);
+  for (int i = ED_PM_LOG_NC - 2; i >= 0; --i) g = EDFIT_FMA_K(g, z, c[i]);
   const double hfsq = (0.5 * f) * f;
   const double dk = (double)k;
   const double w = __builtin_fma(s, hfsq + z * g, dk * ED_PM_LN2_LO);
@@ -62,22 +70,22 @@ __device__ __forceinline__ void digamma_trigamma_nolog(double x, double& xs, dou
   const double w = r * r;
   // psi(x)  = ln x - 1/(2x) - sum_k B_2k / (2k x^2k)
   double p = 1.0 / 12.0;                       // B14/14
-  p = ed_pm_fma_k(p, w, -691.0 / 32760.0);   // B12/12
-  p = ed_pm_fma_k(p, w, 1.0 / 132.0);        // B10/10
-  p = ed_pm_fma_k(p, w, -1.0 / 240.0);       // B8/8
-  p = ed_pm_fma_k(p, w, 1.0 / 252.0);        // B6/6
-  p = ed_pm_fma_k(p, w, -1.0 / 120.0);       // B4/4
-  p = ed_pm_fma_k(p, w, 1.0 / 12.0);         // B2/2
+  p = EDFIT_FMA_K(p, w, -691.0 / 32760.0);   // B12/12
+  p = EDFIT_FMA_K(p, w, 1.0 / 132.0);        // B10/10
+  p = EDFIT_FMA_K(p, w, -1.0 / 240.0);       // B8/8
+  p = EDFIT_FMA_K(p, w, 1.0 / 252.0);        // B6/6
+  p = EDFIT_FMA_K(p, w, -1.0 / 120.0);       // B4/4
+  p = EDFIT_FMA_K(p, w, 1.0 / 12.0);         // B2/2
   psi_rest = (-0.5 * r - p * w) - s0;          // psi(x_original) = ln(xs) + psi_rest
   xs = x;
   // psi'(x) = 1/x + 1/(2x^2) + sum_k B_2k / x^(2k+1)
   double q = 7.0 / 6.0;                        // B14
-  q = ed_pm_fma_k(q, w, -691.0 / 2730.0);    // B12
-  q = ed_pm_fma_k(q, w, 5.0 / 66.0);         // B10
-  q = ed_pm_fma_k(q, w, -1.0 / 30.0);        // B8
-  q = ed_pm_fma_k(q, w, 1.0 / 42.0);         // B6
-  q = ed_pm_fma_k(q, w, -1.0 / 30.0);        // B4
-  q = ed_pm_fma_k(q, w, 1.0 / 6.0);          // B2
+  q = EDFIT_FMA_K(q, w, -691.0 / 2730.0);    // B12
+  q = EDFIT_FMA_K(q, w, 5.0 / 66.0);         // B10
+  q = EDFIT_FMA_K(q, w, -1.0 / 30.0);        // B8
+  q = EDFIT_FMA_K(q, w, 1.0 / 42.0);         // B6
+  q = EDFIT_FMA_K(q, w, -1.0 / 30.0);        // B4
+  q = EDFIT_FMA_K(q, w, 1.0 / 6.0);          // B2
   psi1 = __builtin_fma(q * w, r, __builtin_fma(0.5, w, r)) + s1;
 }
 
@@ -116,14 +124,14 @@ __device__ __forceinline__ void digamma_trigamma_nolog_big(double x, double& psi
   const double r = frcp(x);
   const double w = r * r;
   double p = -1.0 / 240.0;                     // B8/8
-  p = ed_pm_fma_k(p, w, 1.0 / 252.0);        // B6/6
-  p = ed_pm_fma_k(p, w, -1.0 / 120.0);       // B4/4
-  p = ed_pm_fma_k(p, w, 1.0 / 12.0);         // B2/2
+  p = EDFIT_FMA_K(p, w, 1.0 / 252.0);        // B6/6
+  p = EDFIT_FMA_K(p, w, -1.0 / 120.0);       // B4/4
+  p = EDFIT_FMA_K(p, w, 1.0 / 12.0);         // B2/2
   psi_rest = -0.5 * r - p * w;
   double q = -1.0 / 30.0;                      // B8
-  q = ed_pm_fma_k(q, w, 1.0 / 42.0);         // B6
-  q = ed_pm_fma_k(q, w, -1.0 / 30.0);        // B4
-  q = ed_pm_fma_k(q, w, 1.0 / 6.0);          // B2
+  q = EDFIT_FMA_K(q, w, 1.0 / 42.0);         // B6
+  q = EDFIT_FMA_K(q, w, -1.0 / 30.0);        // B4
+  q = EDFIT_FMA_K(q, w, 1.0 / 6.0);          // B2
   psi1 = __builtin_fma(q * w, r, __builtin_fma(0.5, w, r));
 }
 

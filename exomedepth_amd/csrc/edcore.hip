@@ -2987,6 +2987,14 @@ static int fit_columns(FitWork& w, const int32_t* d_test, int64_t trs, int64_t t
     if (!sm && (tcs != 1 || trs != rrs)) return ed_fail(ED_ERR_INVALID, "fit_columns: histogram path needs per-sample test columns");
     const int64_t cell_rs = sm ? trs : rrs, cell_cs = sm ? sm_pitch : 1;   // element (e, s) of the counts at e * cell_rs + s * cell_cs
     if (int rc = w.alloc_hist()) return rc;
+    if (const char* poison = getenv("ED_FIT_POISON")) {     // (diagnostic) the histogram workspace starts every fit from a byte pattern: a result that depends on what
+      const int byte = atoi(poison) & 0xff;                // the allocation happened to hold differs with the pattern -- ED_FIT_POISON=165, =0, =255 ...
+      const int64_t slots = std::max({w.cap8 * hg8::kHistGroups, w.cap4 * hg4::kHistGroups, w.cap2 * hg2::kHistGroups});
+      HIP_TRY(hipMemsetAsync(w.hist, byte, (size_t)hg2::kHistHalves * hg2::kHistK * hg2::hist_padded(w.S) * 4, st));
+      HIP_TRY(hipMemsetAsync(w.ov_y, byte, (size_t)slots * w.S * 4, st));
+      HIP_TRY(hipMemsetAsync(w.ov_r, byte, (size_t)slots * w.S * 4, st));
+      HIP_TRY(hipMemsetAsync(w.ovn, byte, (size_t)hg2::kHistGroups * w.S * 4, st));
+    }
     // Which geometries to launch: the one asked for (tests), else the one the previous fit's depth points to, else
     // (first fit of this workspace) all three.  The kernels themselves decide which of the launched ones runs, from
     // THIS fit's depth (fit_hist_runs) -- no host round trip, and a stale hint costs time, never correctness.
